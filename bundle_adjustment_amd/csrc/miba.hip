@@ -1,0 +1,1081 @@
+// miba.hip — C ABI (include/miba.h), device memory, LM loop and PCG driver of libmiba.
+//
+// Replaces ceres::Solve as called at /root/reference/src/BundleAdjustment.cpp:108 with the
+// options of /root/reference/app/main.cpp:21-28: trust-region Levenberg-Marquardt
+//  whose linear step is an implicit-Schur block-Jacobi PCG
+// (App. B.3).  All O(observations) and O(points) arithmetic runs in the HIP kernels of
+// miba_kernels.hpp; the host keeps only the scalar LM state machine.  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/miba.h"
+#include "miba_kernels.hpp"
+#include "miba_plan.hpp"
+
+using namespace miba;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct EvPair {
+  hipEvent_t a, b;
+  int kid;
+};
+
+}  // namespace
+
+struct miba_handle_s {
+  miba_config cfg{};
+  int device = 0;
+  hipStream_t st = nullptr;
+  ncclComm_t comm = nullptr;
+  std::string err;
+  bool has_problem = false;
+
+  Plan plan;                 // global plan (host)
+  // local shard extents
+  int64_t t0 = 0, t1 = 0;    // tiles
+  int64_t slot_base = 0, n_slots = 0, n_obs_local = 0;
+  int32_t pt_base = 0, n_pt = 0;   // sorted-point range owned
+  int32_t n_cam = 0;
+  int64_t n_tiles = 0, n_rows = 0;
+  int64_t n_valid_global = 0;
+
+  // device arrays
+  Tile* d_tiles = nullptr; Group* d_grps = nullptr;
+  int32_t *d_idx = nullptr, *d_ocam = nullptr, *d_tile_cams = nullptr, *d_slab_row = nullptr, *d_cam_row_off = nullptr;
+  int2* d_pt_rng = nullptr;
+  uint8_t* d_cam_active = nullptr;
+  double *d_oxy = nullptr, *d_cam = nullptr, *d_cam_cand = nullptr, *d_ct = nullptr, *d_sc = nullptr;
+  double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
+  double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
+  double *d_slab64 = nullptr, *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
+  double *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pq = nullptr, *d_probe = nullptr;
+  double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
+  double *d_sum = nullptr, *d_max = nullptr;   // [S_COUNT] each
+  Ctl* d_ctl = nullptr;
+  std::vector<void*> allocs;
+
+  // host pinned
+  double* h_scal = nullptr;   // 2*S_COUNT
+  Ctl* h_ctl = nullptr;
+
+  bool jac_valid = false;     // d_J holds the (scaled) Jacobian of the current state
+  bool scale_valid = false;
+  std::vector<miba_iteration> iters;
+
+  // kernel timing
+  std::vector<EvPair> ev_free, ev_busy;
+  miba_kernel_times kt{};
+};
+
+namespace {
+
+int fail(miba_handle h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) return fail(h, MIBA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define NCCLCHK(h, call)                                                                         \
+  do {                                                                                           \
+    ncclResult_t r_ = (call);                                                                    \
+    if (r_ != ncclSuccess) return fail(h, MIBA_ERR_RCCL, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+int dev_alloc(miba_handle h, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(h, MIBA_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  h->allocs.push_back(p);
+  *out = (T*)p;
+  return MIBA_OK;
+}
+
+template <typename T>
+int upload(miba_handle h, T* dst, const T* src, size_t count) {
+  if (!count) return MIBA_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return MIBA_OK;
+}
+
+void free_problem(miba_handle h) {
+  for (void* p : h->allocs) (void)hipFree(p);
+  h->allocs.clear();
+  h->has_problem = false;
+  h->jac_valid = false;
+  h->scale_valid = false;
+}
+
+// ---- kernel timing -------------------------------------------------------------------------
+void drain_events(miba_handle h) {
+  for (auto& e : h->ev_busy) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      h->kt.total_ms[e.kid] += ms;
+      h->kt.launches[e.kid] += 1;
+    }
+    h->ev_free.push_back(e);
+  }
+  h->ev_busy.clear();
+}
+
+struct Timed {
+  miba_handle h;
+  EvPair e{};
+  bool on = false;
+  Timed(miba_handle h_, int kid) : h(h_) {
+    if (h->ev_free.empty()) {
+      if (h->ev_busy.size() >= 4096) return;  // resolved at the next host sync
+      EvPair n{};
+      if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+      h->ev_free.push_back(n);
+    }
+    e = h->ev_free.back();
+    h->ev_free.pop_back();
+    e.kid = kid;
+    on = (hipEventRecord(e.a, h->st) == hipSuccess);
+    if (!on) h->ev_free.push_back(e);
+  }
+  ~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(e.b, h->st);
+    h->ev_busy.push_back(e);
+  }
+};
+
+int sync_stream(miba_handle h) {
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  drain_events(h);
+  return MIBA_OK;
+}
+
+inline int nblk(size_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+int allreduce(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
+  if (!h->comm) return MIBA_OK;
+  NCCLCHK(h, ncclAllReduce(buf, buf, n, ncclDouble, op, h->comm, h->st));
+  return MIBA_OK;
+}
+
+// ---- building blocks -----------------------------------------------------------------------
+int launch_cam_tables(miba_handle h, const double* cam) {
+  hipLaunchKernelGGL(k_cam_tables, dim3(nblk(h->n_cam, 128)), dim3(128), 0, h->st, h->n_cam, cam, h->d_ct);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
+// residual + Jacobian at (cam, X); cost -> d_sum[S_COST] (all-reduced)
+int eval_jac(miba_handle h, const double* cam, const double* X, bool scaled) {
+  int rc = launch_cam_tables(h, cam);
+  if (rc) return rc;
+  if (h->n_tiles) {
+    Timed t(h, MIBA_K_EVAL_JAC);
+    hipLaunchKernelGGL(k_eval<true>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
+                       h->d_ocam, h->d_oxy, h->d_ct, X, scaled ? h->d_sc : nullptr, scaled ? h->d_sp : nullptr, h->d_J,
+                       h->d_part_tile);
+  }
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
+  HIPCHK(h, hipGetLastError());
+  return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
+}
+
+int eval_cost(miba_handle h, const double* cam, const double* X) {
+  int rc = launch_cam_tables(h, cam);
+  if (rc) return rc;
+  if (h->n_tiles) {
+    Timed t(h, MIBA_K_EVAL_COST);
+    hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
+                       h->d_ocam, h->d_oxy, h->d_ct, X, nullptr, nullptr, nullptr, h->d_part_tile);
+  }
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
+  HIPCHK(h, hipGetLastError());
+  return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
+}
+
+constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 + 4) * sizeof(double);
+
+// K2 + camera reductions + camera blocks; fills Cinv, gp, Minv, Dc2, rhs and the gradient norms
+int schur_init(miba_handle h, double radius, const miba_options* o) {
+  const double inv_r = 1.0 / radius;
+  HIPCHK(h, hipMemsetAsync(&h->d_ctl->fail, 0, sizeof(int32_t), h->st));
+  if (h->n_tiles) {
+    Timed t(h, MIBA_K_SCHUR_INIT);
+    hipLaunchKernelGGL(k_schur_init, dim3((unsigned)h->n_tiles), dim3(kChunk), kK2Lds, h->st, h->d_tiles, h->d_grps, h->d_idx,
+                       h->d_pt_rng, h->d_slab_row, h->d_J, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp,
+                       h->d_dgp, h->d_slab64, h->d_ctl);
+  }
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab64,
+                     h->d_camacc);
+  HIPCHK(h, hipGetLastError());
+  int rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
+  if (rc) return rc;
+  const int nb = nblk(h->n_cam, 64);
+  hipLaunchKernelGGL(k_cam_blocks, dim3(nb), dim3(64), 0, h->st, h->n_cam, h->d_camacc, h->d_cam_active, h->d_sc, inv_r,
+                     o->min_lm_diagonal, o->max_lm_diagonal, h->d_Minv, h->d_Dc2, h->d_rhs, h->d_part_small, h->d_ctl);
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 0, 1, h->d_max + S_GMAX_C);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 1, 0, h->d_sum + S_G2_C);
+  HIPCHK(h, hipGetLastError());
+  // point gradient norms (local points), then all-reduce
+  const int nbp = 240;
+  double* pp = h->d_part_small + 2 * (size_t)nb;
+  hipLaunchKernelGGL(k_pt_gradnorm, dim3(nbp), dim3(256), 0, h->st, h->n_pt, h->d_gp, h->d_sp, pp);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 0, 1, h->d_max + S_GMAX_P);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 1, 0, h->d_sum + S_G2_P);
+  HIPCHK(h, hipGetLastError());
+  rc = allreduce(h, h->d_sum + S_G2_P, 1, ncclSum);
+  if (rc) return rc;
+  return allreduce(h, h->d_max + S_GMAX_P, 1, ncclMax);
+}
+
+// y = S x  (x, y: 9*n_cam device vectors)
+int schur_matvec(miba_handle h, const double* x, double* y) {
+  if (h->n_tiles) {
+    Timed t(h, MIBA_K_SCHUR_MATVEC);
+    hipLaunchKernelGGL(k_schur_matvec<0>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
+                       h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_J, h->d_Cinv, x, h->d_slab9, nullptr, h->d_ctl);
+  }
+  hipLaunchKernelGGL(k_cam_reduce9, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
+                     h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->d_ctl);
+  HIPCHK(h, hipGetLastError());
+  return allreduce(h, y, 9 * (size_t)h->n_cam, ncclSum);
+}
+
+// Jacobi scale from the UNSCALED Jacobian currently in d_J
+int make_scale(miba_handle h) {
+  if (h->n_tiles)
+    hipLaunchKernelGGL(k_schur_matvec<1>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
+                       h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_J, nullptr, nullptr, h->d_slab9, h->d_sp, nullptr);
+  hipLaunchKernelGGL(k_cam_reduce9, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
+                     nullptr, nullptr, 0.0, h->d_sc, nullptr);
+  HIPCHK(h, hipGetLastError());
+  int rc = allreduce(h, h->d_sc, 9 * (size_t)h->n_cam, ncclSum);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_make_scale, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_sc, h->d_sc);
+  hipLaunchKernelGGL(k_make_scale, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_sp, h->d_sp);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
+int unit_scale(miba_handle h) {
+  hipLaunchKernelGGL(k_fill, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, 1.0, h->d_sc);
+  hipLaunchKernelGGL(k_fill, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, 1.0, h->d_sp);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
+// ConjugateGradientsSolver::Solve on S y = rhs with x0 = 0.  Solution in d_px.
+int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
+  const size_t n = 9 * (size_t)h->n_cam;
+  double* part_rho = h->d_part_pcg;
+  double* part_pq = h->d_part_pcg + 128;
+  double* part_q = h->d_part_pcg + 256;
+  hipLaunchKernelGGL(pcg_start, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_rhs, h->d_px, h->d_pr, h->d_ctl, part_rho);
+  hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_rho, h->d_ctl);
+  HIPCHK(h, hipGetLastError());
+  if (check_every < 1) check_every = 1;
+  int it = 0;
+  for (;;) {
+    ++it;
+    hipLaunchKernelGGL(pcg_precond, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_Minv, h->d_pr, h->d_pz, h->d_ctl, part_rho);
+    hipLaunchKernelGGL(pcg_dir, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pz, h->d_pp, h->d_ctl, part_rho);
+    hipLaunchKernelGGL(pcg_dir_commit, dim3(1), dim3(256), 0, h->st, h->d_ctl, part_rho);
+    HIPCHK(h, hipGetLastError());
+    int rc = schur_matvec(h, h->d_pp, h->d_pq);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pcg_dot, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pp, h->d_pq, h->d_ctl, part_pq);
+    const int reset = (it % 10 == 0) ? 1 : 0;  // residual_reset_period
+    hipLaunchKernelGGL(pcg_update, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pp, h->d_pq, h->d_rhs, h->d_px, h->d_pr,
+                       h->d_ctl, part_pq, part_q, reset);
+    HIPCHK(h, hipGetLastError());
+    if (reset) {
+      rc = schur_matvec(h, h->d_px, h->d_pz);  // z is free here
+      if (rc) return rc;
+      hipLaunchKernelGGL(pcg_resid, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_rhs, h->d_pz, h->d_px, h->d_pr, h->d_ctl,
+                         part_pq, part_q);
+    }
+    hipLaunchKernelGGL(pcg_check, dim3(1), dim3(256), 0, h->st, h->d_ctl, part_pq, part_q, q_tol, min_it, max_it);
+    HIPCHK(h, hipGetLastError());
+    if (it % check_every == 0 || it >= max_it) {
+      HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
+      rc = sync_stream(h);
+      if (rc) return rc;
+      if (h->h_ctl->done) break;
+      if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
+    }
+  }
+  *n_it = h->h_ctl->n_it;
+  *status = h->h_ctl->status;
+  return MIBA_OK;
+}
+
+// back-substitution, candidate state, model cost change, step / candidate norms
+int backsub_and_candidate(miba_handle h) {
+  if (h->n_tiles) {
+    Timed t(h, MIBA_K_BACKSUB);
+    hipLaunchKernelGGL(k_backsub, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
+                       h->d_pt_rng, h->d_tile_cams, h->d_J, h->d_Cinv, h->d_gp, h->d_px, h->d_sp, h->d_X, h->d_yp, h->d_Xc,
+                       h->d_part_tile);
+  }
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 0, 0, h->d_sum + S_MCC);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 1, 0, h->d_sum + S_DP2);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 2, 0, h->d_sum + S_XP2);
+  HIPCHK(h, hipGetLastError());
+  int rc = allreduce(h, h->d_sum + S_MCC, 3, ncclSum);  // S_MCC, S_DP2, S_XP2 are adjacent
+  if (rc) return rc;
+  const int nb = 120;
+  hipLaunchKernelGGL(k_cam_update, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_cam, h->d_sc, h->d_px, h->d_cam_active,
+                     h->d_cam_cand, h->d_part_small);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 0, 0, h->d_sum + S_DC2);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 1, 0, h->d_sum + S_XC2);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
+int state_norm2(miba_handle h, double* out) {
+  const int nb = 120;
+  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_cam, h->d_cam_active, 9, h->d_part_small);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 1, 0, 0, h->d_sum + S_XC2);
+  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_X, (const uint8_t*)nullptr, 3, h->d_part_small + 128);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small + 128, (size_t)nb, 1, 0, 0, h->d_sum + S_XP2);
+  HIPCHK(h, hipGetLastError());
+  int rc = allreduce(h, h->d_sum + S_XP2, 1, ncclSum);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->h_scal, h->d_sum, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  rc = sync_stream(h);
+  if (rc) return rc;
+  *out = h->h_scal[S_XC2] + h->h_scal[S_XP2];
+  return MIBA_OK;
+}
+
+int read_scalars(miba_handle h) {
+  HIPCHK(h, hipMemcpyAsync(h->h_scal, h->d_sum, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(h->h_scal + S_COUNT, h->d_max, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
+  return sync_stream(h);
+}
+
+// make d_J the scaled Jacobian of the current state (computing the Jacobi scale on first use)
+int ensure_jacobian(miba_handle h, const miba_options* o) {
+  int rc;
+  if (!h->scale_valid) {
+    if (o->jacobi_scaling) {
+      rc = eval_jac(h, h->d_cam, h->d_X, false);
+      if (rc) return rc;
+      rc = make_scale(h);
+      if (rc) return rc;
+    } else {
+      rc = unit_scale(h);
+      if (rc) return rc;
+    }
+    h->scale_valid = true;
+    h->jac_valid = false;
+  }
+  if (!h->jac_valid) {
+    rc = eval_jac(h, h->d_cam, h->d_X, true);
+    if (rc) return rc;
+    h->jac_valid = true;
+  }
+  return MIBA_OK;
+}
+
+void print_progress(const miba_iteration& it, bool header) {
+  if (header)
+    printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter  iter_time  total_time\n");
+  printf("%4d % 8.6e  % 3.2e   %3.2e  %3.2e  % 3.2e  %3.2e   %6d   %3.2e   %3.2e\n", it.iteration, it.cost, it.cost_change,
+         it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius, it.linear_solver_iterations,
+         it.iteration_time_in_seconds, it.cumulative_time_in_seconds);
+  fflush(stdout);
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+void miba_default_options(miba_options* o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 50;
+  o->linear_solver_type = MIBA_ITERATIVE_SCHUR;
+  o->jacobi_scaling = 1;
+  o->max_linear_solver_iterations = 500;
+  o->min_linear_solver_iterations = 0;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->update_state_every_iteration = 0;
+  o->minimizer_progress_to_stdout = 0;
+  o->pcg_check_every = 1;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->eta = 1e-1;
+  o->eta_exact = 1e-12;
+  o->max_solver_time_in_seconds = 1e9;
+}
+
+const char* miba_last_error(miba_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int miba_comm_unique_id(void* out128) {
+  if (!out128) return fail(nullptr, MIBA_ERR_INVALID, "null output");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  NCCLCHK(nullptr, ncclGetUniqueId(&id));
+  memcpy(out128, &id, sizeof(id));
+  return MIBA_OK;
+}
+
+int miba_create(const miba_config* cfg, miba_handle* out) {
+  if (!cfg || !out) return fail(nullptr, MIBA_ERR_INVALID, "null argument");
+  if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size)
+    return fail(nullptr, MIBA_ERR_INVALID, "bad rank/world_size %d/%d", cfg->rank, cfg->world_size);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MIBA_ERR_NO_DEVICE, "no HIP device available (libmiba has no CPU fallback)");
+  int dev = cfg->device_id;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) return fail(nullptr, MIBA_ERR_NO_DEVICE, "hipGetDevice failed");
+  }
+  if (dev >= ndev) return fail(nullptr, MIBA_ERR_INVALID, "device %d out of range (%d devices)", dev, ndev);
+  miba_handle h = new (std::nothrow) miba_handle_s();
+  if (!h) return fail(nullptr, MIBA_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+  h->cfg.comm_unique_id = nullptr;
+  h->device = dev;
+  hipError_t e = hipSetDevice(dev);
+  if (e == hipSuccess) e = hipStreamCreate(&h->st);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_scal, 2 * S_COUNT * sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl));
+  if (e != hipSuccess) {
+    int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
+    delete h;
+    return rc;
+  }
+  e = hipFuncSetAttribute((const void*)k_schur_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK2Lds);
+  if (e != hipSuccess) {
+    int rc = fail(nullptr, MIBA_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    delete h;
+    return rc;
+  }
+  const char* force = getenv("MIBA_FORCE_RCCL");
+  if (cfg->world_size > 1 || (force && force[0] == '1')) {
+    ncclUniqueId id;
+    if (cfg->comm_unique_id) memcpy(&id, cfg->comm_unique_id, sizeof(id));
+    else if (cfg->world_size == 1) {
+      if (ncclGetUniqueId(&id) != ncclSuccess) { delete h; return fail(nullptr, MIBA_ERR_RCCL, "ncclGetUniqueId failed"); }
+    } else { delete h; return fail(nullptr, MIBA_ERR_INVALID, "world_size > 1 needs comm_unique_id"); }
+    ncclResult_t r = ncclCommInitRank(&h->comm, cfg->world_size, id, cfg->rank);
+    if (r != ncclSuccess) {
+      int rc = fail(nullptr, MIBA_ERR_RCCL, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+      delete h;
+      return rc;
+    }
+  }
+  *out = h;
+  return MIBA_OK;
+}
+
+int miba_destroy(miba_handle h) {
+  if (!h) return MIBA_OK;
+  (void)hipSetDevice(h->device);
+  if (h->st) (void)hipStreamSynchronize(h->st);
+  free_problem(h);
+  drain_events(h);
+  for (auto& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (h->comm) (void)ncclCommDestroy(h->comm);
+  if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+  if (h->st) (void)hipStreamDestroy(h->st);
+  delete h;
+  return MIBA_OK;
+}
+
+int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid_obs, int64_t* n_tiles, int64_t* n_slots,
+                     int64_t* tiles_per_rank, int64_t* obs_per_rank) {
+  if (!p) return fail(nullptr, MIBA_ERR_INVALID, "null problem");
+  Plan P;
+  const char* po = getenv("MIBA_POINT_ORDER");
+  int rc = build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, world_size, po ? atoi(po) : 1);
+  if (rc) return fail(nullptr, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d)", rc);
+  if (n_valid_obs) *n_valid_obs = P.n_valid;
+  if (n_tiles) *n_tiles = (int64_t)P.tiles.size();
+  if (n_slots) *n_slots = P.n_slots;
+  for (int r = 0; r < world_size; ++r) {
+    if (tiles_per_rank) tiles_per_rank[r] = P.shard_tile[r + 1] - P.shard_tile[r];
+    if (obs_per_rank) {
+      int64_t n = 0;
+      for (int64_t t = P.shard_tile[r]; t < P.shard_tile[r + 1]; ++t)
+        for (int32_t s = P.tiles[t].slot0; s < P.tiles[t].slot0 + P.tiles[t].nslot; ++s) n += P.idx[s] >= 0;
+      obs_per_rank[r] = n;
+    }
+  }
+  return MIBA_OK;
+}
+
+int miba_set_problem(miba_handle h, const miba_problem* p) {
+  if (!h || !p) return fail(h, MIBA_ERR_INVALID, "null argument");
+  if (!p->R || !p->T || !p->K || !p->X || (p->n_obs > 0 && (!p->obs_cam || !p->obs_pt || !p->obs_xy)))
+    return fail(h, MIBA_ERR_INVALID, "null problem array");
+  HIPCHK(h, hipSetDevice(h->device));
+  free_problem(h);
+  const char* po = getenv("MIBA_POINT_ORDER");
+  Plan& P = h->plan;
+  int rc = build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->cfg.world_size,
+                      po ? atoi(po) : 1);
+  if (rc) return fail(h, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", rc);
+  h->n_cam = p->n_cam;
+  h->n_valid_global = P.n_valid;
+  h->t0 = P.shard_tile[h->cfg.rank];
+  h->t1 = P.shard_tile[h->cfg.rank + 1];
+  h->n_tiles = h->t1 - h->t0;
+  // local extents
+  std::vector<Tile> tiles(P.tiles.begin() + h->t0, P.tiles.begin() + h->t1);
+  int32_t g0 = 0, g1 = 0, tc0 = 0, tc1 = 0;
+  if (h->n_tiles) {
+    g0 = tiles.front().grp0; g1 = tiles.back().grp0 + tiles.back().ngrp;
+    tc0 = tiles.front().cam0; tc1 = tiles.back().cam0 + tiles.back().ncs;
+    h->slot_base = tiles.front().slot0;
+    h->n_slots = (int64_t)tiles.back().slot0 + tiles.back().nslot - h->slot_base;
+  } else {
+    h->slot_base = 0; h->n_slots = 0;
+  }
+  std::vector<Group> grps(P.groups.begin() + g0, P.groups.begin() + g1);
+  h->pt_base = grps.empty() ? 0 : grps.front().pt0;
+  h->n_pt = grps.empty() ? 0 : grps.back().pt0 + grps.back().npt - h->pt_base;
+  const int32_t chunk_base = (int32_t)(h->slot_base / kChunk);
+  for (auto& t : tiles) { t.grp0 -= g0; t.cam0 -= tc0; t.slot0 -= (int32_t)h->slot_base; }
+  for (auto& g : grps) { g.chunk0 -= chunk_base; g.pt0 -= h->pt_base; }
+  // camera-major slab rows for the local (tile, camera-slot) pairs
+  const int64_t n_rows = tc1 - tc0;
+  h->n_rows = n_rows;
+  std::vector<int32_t> cam_row_off(p->n_cam + 1, 0), slab_row(n_rows ? n_rows : 1);
+  for (int64_t e = 0; e < n_rows; ++e) cam_row_off[P.tile_cams[tc0 + e] + 1]++;
+  for (int c = 0; c < p->n_cam; ++c) cam_row_off[c + 1] += cam_row_off[c];
+  {
+    std::vector<int32_t> cur(cam_row_off.begin(), cam_row_off.end() - 1);
+    for (int64_t e = 0; e < n_rows; ++e) slab_row[e] = cur[P.tile_cams[tc0 + e]]++;
+  }
+  // observations in chunk-SoA order, point ranges
+  std::vector<double> oxy((size_t)(h->n_slots ? h->n_slots : 1) * 2, 0.0);
+  h->n_obs_local = 0;
+  for (int64_t s = 0; s < h->n_slots; ++s) {
+    const int64_t o = P.slot_orig[h->slot_base + s];
+    if (o < 0) continue;
+    const size_t chunk = (size_t)(s / kChunk), lane = (size_t)(s % kChunk);
+    oxy[chunk * 2 * kChunk + lane] = p->obs_xy[2 * o];
+    oxy[chunk * 2 * kChunk + kChunk + lane] = p->obs_xy[2 * o + 1];
+    h->n_obs_local++;
+  }
+  std::vector<int2> pt_rng(h->n_pt ? h->n_pt : 1);
+  for (int32_t q = 0; q < h->n_pt; ++q) {
+    pt_rng[q].x = P.pt_first[h->pt_base + q] - (int32_t)h->slot_base;
+    pt_rng[q].y = P.pt_count[h->pt_base + q];
+  }
+#define ALLOC(ptr, n)                        \
+  do {                                       \
+    rc = dev_alloc(h, &(ptr), (size_t)(n));  \
+    if (rc) { free_problem(h); return rc; }  \
+  } while (0)
+#define UP(dst, src, n)                      \
+  do {                                       \
+    rc = upload(h, dst, src, (size_t)(n));   \
+    if (rc) { free_problem(h); return rc; }  \
+  } while (0)
+  const size_t nc = (size_t)p->n_cam, np = (size_t)h->n_pt, ns = (size_t)h->n_slots, nt = (size_t)h->n_tiles;
+  ALLOC(h->d_tiles, nt); ALLOC(h->d_grps, grps.size());
+  ALLOC(h->d_idx, ns); ALLOC(h->d_ocam, ns); ALLOC(h->d_tile_cams, n_rows); ALLOC(h->d_slab_row, n_rows);
+  ALLOC(h->d_cam_row_off, nc + 1); ALLOC(h->d_pt_rng, np); ALLOC(h->d_cam_active, nc);
+  ALLOC(h->d_oxy, 2 * ns);
+  ALLOC(h->d_cam, 9 * nc); ALLOC(h->d_cam_cand, 9 * nc); ALLOC(h->d_ct, (size_t)kCamTabStride * nc); ALLOC(h->d_sc, 9 * nc);
+  ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
+  ALLOC(h->d_J, (size_t)kJComp * ns);
+  ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
+  ALLOC(h->d_slab64, (size_t)kK2W * n_rows); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
+  ALLOC(h->d_camacc, (size_t)kK2W * nc); ALLOC(h->d_Minv, 81 * nc); ALLOC(h->d_Dc2, 9 * nc); ALLOC(h->d_rhs, 9 * nc);
+  ALLOC(h->d_px, 9 * nc); ALLOC(h->d_pr, 9 * nc); ALLOC(h->d_pz, 9 * nc); ALLOC(h->d_pp, 9 * nc); ALLOC(h->d_pq, 9 * nc);
+  ALLOC(h->d_probe, 9 * nc);
+  ALLOC(h->d_part_tile, 4 * nt + 4);
+  ALLOC(h->d_part_small, 2 * (size_t)nblk(nc, 64) + 2 * 240 + 512);
+  ALLOC(h->d_part_pcg, 384);
+  ALLOC(h->d_sum, S_COUNT); ALLOC(h->d_max, S_COUNT);
+  ALLOC(h->d_ctl, 1);
+  UP(h->d_tiles, tiles.data(), nt);
+  UP(h->d_grps, grps.data(), grps.size());
+  UP(h->d_idx, P.idx.data() + h->slot_base, ns);
+  UP(h->d_ocam, P.ocam.data() + h->slot_base, ns);
+  UP(h->d_tile_cams, P.tile_cams.data() + tc0, n_rows);
+  UP(h->d_slab_row, slab_row.data(), n_rows);
+  UP(h->d_cam_row_off, cam_row_off.data(), nc + 1);
+  UP(h->d_pt_rng, pt_rng.data(), np);
+  UP(h->d_cam_active, P.cam_active.data(), nc);
+  UP(h->d_oxy, oxy.data(), 2 * ns);
+#undef ALLOC
+#undef UP
+  HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
+  HIPCHK(h, hipMemsetAsync(h->d_max, 0, S_COUNT * sizeof(double), h->st));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(Ctl), h->st));
+  HIPCHK(h, hipMemsetAsync(h->d_part_pcg, 0, 384 * sizeof(double), h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  // the big host-side index arrays are not needed any more, except slot_orig / pt_orig (evaluate, get_state)
+  std::vector<int32_t>().swap(P.idx);
+  std::vector<int32_t>().swap(P.ocam);
+  h->has_problem = true;
+  memset(&h->kt, 0, sizeof(h->kt));
+  return miba_set_state(h, p->R, p->T, p->K, p->X);
+}
+
+int miba_set_state(miba_handle h, const double* R, const double* T, const double* K, const double* X) {
+  if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
+  if (!R || !T || !K || !X) return fail(h, MIBA_ERR_INVALID, "null state array");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> cam(9 * (size_t)h->n_cam);
+  for (int c = 0; c < h->n_cam; ++c) {
+    double* o = cam.data() + 9 * (size_t)c;
+    o[0] = R[3 * c]; o[1] = R[3 * c + 1]; o[2] = R[3 * c + 2];
+    o[3] = T[3 * c]; o[4] = T[3 * c + 1]; o[5] = T[3 * c + 2];
+    o[6] = K[6 * c]; o[7] = K[6 * c + 4]; o[8] = K[6 * c + 5];   // src/BalDataloader.cpp:143-148
+  }
+  std::vector<double> pts(3 * (size_t)(h->n_pt ? h->n_pt : 1));
+  for (int32_t q = 0; q < h->n_pt; ++q) {
+    const size_t o = (size_t)h->plan.pt_orig[h->pt_base + q];
+    pts[3 * (size_t)q] = X[3 * o]; pts[3 * (size_t)q + 1] = X[3 * o + 1]; pts[3 * (size_t)q + 2] = X[3 * o + 2];
+  }
+  int rc = upload(h, h->d_cam, cam.data(), cam.size());
+  if (rc) return rc;
+  rc = upload(h, h->d_X, pts.data(), 3 * (size_t)h->n_pt);
+  if (rc) return rc;
+  h->jac_valid = false;
+  h->scale_valid = false;
+  return MIBA_OK;
+}
+
+int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
+  if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> cam(9 * (size_t)h->n_cam);
+  HIPCHK(h, hipMemcpyAsync(cam.data(), h->d_cam, cam.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  for (int c = 0; c < h->n_cam; ++c) {
+    if (!h->plan.cam_active[c]) continue;   // blocks that are not in the problem stay untouched
+    const double* o = cam.data() + 9 * (size_t)c;
+    if (R) { R[3 * c] = o[0]; R[3 * c + 1] = o[1]; R[3 * c + 2] = o[2]; }
+    if (T) { T[3 * c] = o[3]; T[3 * c + 1] = o[4]; T[3 * c + 2] = o[5]; }
+    if (K) { K[6 * c] = o[6]; K[6 * c + 1] = o[6]; K[6 * c + 2] = 0.0; K[6 * c + 3] = 0.0; K[6 * c + 4] = o[7]; K[6 * c + 5] = o[8]; }
+  }
+  if (!X) return MIBA_OK;
+  const size_t n_act = h->plan.pt_orig.size();
+  std::vector<double> pts(3 * (n_act ? n_act : 1), 0.0);
+  if (h->comm && h->cfg.world_size > 1) {
+    // every rank contributes its own points to a zero-filled buffer; sum = gather
+    double* d_all = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_all, 3 * (n_act ? n_act : 1) * sizeof(double)));
+    hipError_t e = hipMemsetAsync(d_all, 0, 3 * n_act * sizeof(double), h->st);
+    if (e == hipSuccess && h->n_pt)
+      e = hipMemcpyAsync(d_all + 3 * (size_t)h->pt_base, h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToDevice, h->st);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = ncclAllReduce(d_all, d_all, 3 * n_act, ncclDouble, ncclSum, h->comm, h->st);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(pts.data(), d_all, 3 * n_act * sizeof(double), hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    (void)hipFree(d_all);
+    if (r != ncclSuccess) return fail(h, MIBA_ERR_RCCL, "all-gather of points failed: %s", ncclGetErrorString(r));
+    if (e != hipSuccess) return fail(h, MIBA_ERR_HIP, "point download failed: %s", hipGetErrorString(e));
+    for (size_t s = 0; s < n_act; ++s) {
+      const size_t o = (size_t)h->plan.pt_orig[s];
+      X[3 * o] = pts[3 * s]; X[3 * o + 1] = pts[3 * s + 1]; X[3 * o + 2] = pts[3 * s + 2];
+    }
+  } else {
+    if (h->n_pt) {
+      HIPCHK(h, hipMemcpyAsync(pts.data(), h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToHost, h->st));
+      HIPCHK(h, hipStreamSynchronize(h->st));
+    }
+    for (int32_t q = 0; q < h->n_pt; ++q) {
+      const size_t o = (size_t)h->plan.pt_orig[h->pt_base + q];
+      X[3 * o] = pts[3 * (size_t)q]; X[3 * o + 1] = pts[3 * (size_t)q + 1]; X[3 * o + 2] = pts[3 * (size_t)q + 2];
+    }
+  }
+  return MIBA_OK;
+}
+
+int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_cam, double* jac_pt, double* grad_cam,
+                  double* grad_pt) {
+  if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
+  HIPCHK(h, hipSetDevice(h->device));
+  miba_options o;
+  miba_default_options(&o);
+  int rc = eval_jac(h, h->d_cam, h->d_X, false);
+  if (rc) return rc;
+  h->jac_valid = false;  // d_J now holds the unscaled Jacobian
+  HIPCHK(h, hipMemcpyAsync(h->h_scal, h->d_sum, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
+  rc = sync_stream(h);
+  if (rc) return rc;
+  if (cost) *cost = h->h_scal[S_COST];
+  const Plan& P = h->plan;
+  if (residuals || jac_cam || jac_pt) {
+    if (residuals) memset(residuals, 0, sizeof(double) * 2 * (size_t)P.n_obs_in);
+    if (jac_cam) memset(jac_cam, 0, sizeof(double) * 18 * (size_t)P.n_obs_in);
+    if (jac_pt) memset(jac_pt, 0, sizeof(double) * 6 * (size_t)P.n_obs_in);
+    std::vector<double> J((size_t)kJComp * (size_t)(h->n_slots ? h->n_slots : 1));
+    if (h->n_slots) {
+      HIPCHK(h, hipMemcpyAsync(J.data(), h->d_J, J.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+      HIPCHK(h, hipStreamSynchronize(h->st));
+    }
+    for (int64_t s = 0; s < h->n_slots; ++s) {
+      const int64_t ob = P.slot_orig[h->slot_base + s];
+      if (ob < 0) continue;
+      const double* c = J.data() + (size_t)(s / kChunk) * kJComp * kChunk + (size_t)(s % kChunk);
+      if (jac_cam) for (int k = 0; k < 18; ++k) jac_cam[18 * ob + k] = c[(size_t)k * kChunk];
+      if (jac_pt) for (int k = 0; k < 6; ++k) jac_pt[6 * ob + k] = c[(size_t)(18 + k) * kChunk];
+      if (residuals) { residuals[2 * ob] = c[(size_t)24 * kChunk]; residuals[2 * ob + 1] = c[(size_t)25 * kChunk]; }
+    }
+  }
+  if (grad_cam || grad_pt) {
+    rc = unit_scale(h);
+    if (rc) return rc;
+    h->scale_valid = false;
+    rc = schur_init(h, 1e4, &o);   // F'r and E'r do not depend on the radius
+    if (rc) return rc;
+    std::vector<double> acc((size_t)kK2W * h->n_cam), gpv(3 * (size_t)(h->n_pt ? h->n_pt : 1));
+    HIPCHK(h, hipMemcpyAsync(acc.data(), h->d_camacc, acc.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    if (h->n_pt) HIPCHK(h, hipMemcpyAsync(gpv.data(), h->d_gp, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    rc = sync_stream(h);
+    if (rc) return rc;
+    if (grad_cam)
+      for (int c = 0; c < h->n_cam; ++c)
+        for (int k = 0; k < 9; ++k) grad_cam[9 * (size_t)c + k] = acc[(size_t)kK2W * c + 54 + k];
+    if (grad_pt) {
+      memset(grad_pt, 0, sizeof(double) * 3 * (size_t)P.n_pt_in);
+      for (int32_t q = 0; q < h->n_pt; ++q) {
+        const size_t ob = (size_t)P.pt_orig[h->pt_base + q];
+        for (int k = 0; k < 3; ++k) grad_pt[3 * ob + k] = gpv[3 * (size_t)q + k];
+      }
+    }
+  }
+  return MIBA_OK;
+}
+
+int miba_linear_step(miba_handle h, const miba_options* opt, double radius, double* y_cam, double* y_pt, double* rhs,
+                     const double* probe, double* s_probe, int32_t* n_cg, double* model_cost_change) {
+  if (!h || !h->has_problem || !opt) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
+  if (!(radius > 0.0)) return fail(h, MIBA_ERR_INVALID, "radius must be positive");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->scale_valid = false;
+  h->jac_valid = false;
+  int rc = ensure_jacobian(h, opt);
+  if (rc) return rc;
+  rc = schur_init(h, radius, opt);
+  if (rc) return rc;
+  const size_t n = 9 * (size_t)h->n_cam;
+  int it = 0, st = 0;
+  const double q_tol = (opt->linear_solver_type == MIBA_ITERATIVE_SCHUR) ? opt->eta : opt->eta_exact;
+  rc = pcg_solve(h, q_tol, opt->min_linear_solver_iterations, opt->max_linear_solver_iterations, opt->pcg_check_every, &it, &st);
+  if (rc) return rc;
+  if (n_cg) *n_cg = it;
+  rc = backsub_and_candidate(h);
+  if (rc) return rc;
+  rc = read_scalars(h);
+  if (rc) return rc;
+  if (h->h_ctl->fail) return fail(h, MIBA_ERR_INVALID, "Cholesky failure in Schur init");
+  if (model_cost_change) *model_cost_change = h->h_scal[S_MCC];
+  if (y_cam) HIPCHK(h, hipMemcpy(y_cam, h->d_px, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (rhs) HIPCHK(h, hipMemcpy(rhs, h->d_rhs, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (y_pt) {
+    memset(y_pt, 0, sizeof(double) * 3 * (size_t)h->plan.n_pt_in);
+    std::vector<double> v(3 * (size_t)(h->n_pt ? h->n_pt : 1));
+    if (h->n_pt) HIPCHK(h, hipMemcpy(v.data(), h->d_yp, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToHost));
+    for (int32_t q = 0; q < h->n_pt; ++q) {
+      const size_t ob = (size_t)h->plan.pt_orig[h->pt_base + q];
+      for (int k = 0; k < 3; ++k) y_pt[3 * ob + k] = v[3 * (size_t)q + k];
+    }
+  }
+  if (probe && s_probe) {
+    HIPCHK(h, hipMemcpy(h->d_probe, probe, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemsetAsync(&h->d_ctl->done, 0, sizeof(int32_t), h->st));
+    rc = schur_matvec(h, h->d_probe, h->d_pq);
+    if (rc) return rc;
+    rc = sync_stream(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(s_probe, h->d_pq, n * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return MIBA_OK;
+}
+
+int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback cb, void* user, miba_summary* summary) {
+  if (!h || !h->has_problem || !opt) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
+  HIPCHK(h, hipSetDevice(h->device));
+  const miba_options o = *opt;
+  const double t_start = now_s();
+  double t_callbacks = 0.0, t_linear = 0.0, t_jac = 0.0, t_res = 0.0;
+  h->iters.clear();
+  miba_summary S;
+  memset(&S, 0, sizeof(S));
+  S.termination_type = MIBA_NO_CONVERGENCE;
+  S.num_residual_blocks = (int32_t)std::min<int64_t>(h->n_valid_global, INT32_MAX);
+  S.num_active_cameras = h->plan.n_active_cam;
+  S.num_active_points = (int32_t)h->plan.pt_orig.size();
+  snprintf(S.message, sizeof(S.message), "Maximum number of iterations reached.");
+  const double q_tol = (o.linear_solver_type == MIBA_ITERATIVE_SCHUR) ? o.eta : o.eta_exact;
+  int rc;
+
+  // best-state buffers: d_cam_cand / d_Xc double as candidates, so keep the best state on the host side of
+  // the swap: x (d_cam, d_X) is always the last ACCEPTED state, which in the monotonic algorithm is also
+  // the minimum-cost state.
+
+  // IterationZero
+  double x_norm2 = 0.0;
+  rc = state_norm2(h, &x_norm2);
+  if (rc) return rc;
+  double x_norm = sqrt(x_norm2);
+  h->scale_valid = false;
+  h->jac_valid = false;
+  double tj = now_s();
+  rc = ensure_jacobian(h, &o);
+  if (rc) return rc;
+  double radius = o.initial_trust_region_radius;
+  double decrease_factor = 2.0;
+  int consecutive_invalid = 0;
+  rc = schur_init(h, radius, &o);
+  if (rc) return rc;
+  rc = read_scalars(h);
+  if (rc) return rc;
+  t_jac += now_s() - tj;
+  double x_cost = h->h_scal[S_COST];
+  S.initial_cost = x_cost;
+  miba_iteration it;
+  memset(&it, 0, sizeof(it));
+  it.iteration = 0;
+  it.cost = x_cost;
+  it.gradient_max_norm = fmax(h->h_scal[S_COUNT + S_GMAX_C], h->h_scal[S_COUNT + S_GMAX_P]);
+  it.gradient_norm = sqrt(h->h_scal[S_G2_C] + h->h_scal[S_G2_P]);
+  it.trust_region_radius = radius;
+  it.eta = o.eta;
+  it.iteration_time_in_seconds = now_s() - t_start;
+  it.cumulative_time_in_seconds = it.iteration_time_in_seconds;
+  bool schur_ready = true;   // schur_init done for (current J, current radius)
+  bool user_stop = false;
+
+  for (;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (it.iteration > 0) {
+      if (it.step_is_successful) S.num_successful_steps++; else S.num_unsuccessful_steps++;
+    }
+    it.trust_region_radius = radius;
+    h->iters.push_back(it);
+    if (o.minimizer_progress_to_stdout && h->cfg.rank == 0) print_progress(it, it.iteration == 0);
+    if (cb) {
+      const double tc = now_s();
+      const int r = cb(&it, user);
+      t_callbacks += now_s() - tc;
+      if (r == MIBA_SOLVER_ABORT) { S.termination_type = MIBA_USER_FAILURE; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_ABORT."); user_stop = true; }
+      else if (r == MIBA_SOLVER_TERMINATE_SUCCESSFULLY) { S.termination_type = MIBA_USER_SUCCESS; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_TERMINATE_SUCCESSFULLY."); user_stop = true; }
+    }
+    if (user_stop) break;
+    if (now_s() - t_start - t_callbacks >= o.max_solver_time_in_seconds) { snprintf(S.message, sizeof(S.message), "Maximum solver time reached."); break; }
+    if (it.iteration >= o.max_num_iterations) break;
+    if (it.gradient_max_norm <= o.gradient_tolerance) {
+      S.termination_type = MIBA_CONVERGENCE;
+      snprintf(S.message, sizeof(S.message), "Gradient tolerance reached.");
+      break;
+    }
+    if (radius < o.min_trust_region_radius) {
+      S.termination_type = MIBA_CONVERGENCE;
+      snprintf(S.message, sizeof(S.message), "Minimum trust region radius reached.");
+      break;
+    }
+    const double t_it = now_s();
+    const miba_iteration prev = it;
+    memset(&it, 0, sizeof(it));
+    it.iteration = prev.iteration + 1;
+    it.eta = o.eta;
+
+    // ComputeTrustRegionStep
+    const double tl = now_s();
+    if (!schur_ready) {
+      rc = schur_init(h, radius, &o);
+      if (rc) return rc;
+    }
+    schur_ready = false;
+    int n_cg = 0, cg_status = 0;
+    rc = pcg_solve(h, q_tol, o.min_linear_solver_iterations, o.max_linear_solver_iterations, o.pcg_check_every, &n_cg, &cg_status);
+    if (rc) return rc;
+    it.linear_solver_iterations = n_cg;
+    S.num_linear_solver_iterations += n_cg;
+    rc = backsub_and_candidate(h);
+    if (rc) return rc;
+    rc = read_scalars(h);
+    if (rc) return rc;
+    t_linear += now_s() - tl;
+    const double mcc = h->h_scal[S_MCC];
+    const bool ls_failed = (cg_status == 2) || h->h_ctl->fail || !std::isfinite(mcc);
+    it.model_cost_change = ls_failed ? 0.0 : mcc;
+    it.step_is_valid = (!ls_failed && mcc > 0.0);
+    if (!it.step_is_valid) {
+      // HandleInvalidStep
+      it.cost = x_cost; it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      if (++consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
+        S.termination_type = MIBA_FAILURE;
+        snprintf(S.message, sizeof(S.message), "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d",
+                 o.max_num_consecutive_invalid_steps);
+        it.trust_region_radius = radius;
+        it.iteration_time_in_seconds = now_s() - t_it;
+        it.cumulative_time_in_seconds = now_s() - t_start - t_callbacks;
+        h->iters.push_back(it);
+        S.num_unsuccessful_steps++;
+        break;
+      }
+      radius *= 0.5;  // StepIsInvalid
+      it.iteration_time_in_seconds = now_s() - t_it;
+      it.cumulative_time_in_seconds = now_s() - t_start - t_callbacks;
+      continue;
+    }
+    consecutive_invalid = 0;
+    const double tr = now_s();
+    rc = eval_cost(h, h->d_cam_cand, h->d_Xc);
+    if (rc) return rc;
+    rc = read_scalars(h);
+    if (rc) return rc;
+    t_res += now_s() - tr;
+    double cand_cost = h->h_scal[S_COST];
+    if (!std::isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+    it.step_norm = sqrt(h->h_scal[S_DC2] + h->h_scal[S_DP2]);
+    const double cand_norm = sqrt(h->h_scal[S_XC2] + h->h_scal[S_XP2]);
+    it.cost_change = x_cost - cand_cost;
+    it.relative_decrease = it.cost_change / mcc;
+    bool converged = false;
+    if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
+      S.termination_type = MIBA_CONVERGENCE;
+      snprintf(S.message, sizeof(S.message), "Parameter tolerance reached. Relative step_norm: %e <= %e.",
+               it.step_norm / (x_norm + o.parameter_tolerance), o.parameter_tolerance);
+      converged = true;
+    } else if (fabs(it.cost_change) <= o.function_tolerance * x_cost) {
+      S.termination_type = MIBA_CONVERGENCE;
+      snprintf(S.message, sizeof(S.message), "Function tolerance reached. |cost_change|/cost: %e <= %e",
+               fabs(it.cost_change) / x_cost, o.function_tolerance);
+      converged = true;
+    }
+    if (converged) {
+      it.cost = x_cost; it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      it.trust_region_radius = radius;
+      it.iteration_time_in_seconds = now_s() - t_it;
+      it.cumulative_time_in_seconds = now_s() - t_start - t_callbacks;
+      h->iters.push_back(it);
+      S.num_unsuccessful_steps++;
+      break;
+    }
+    if (it.relative_decrease > o.min_relative_decrease) {
+      // HandleSuccessfulStep: x <- candidate, re-evaluate
+      std::swap(h->d_cam, h->d_cam_cand);
+      std::swap(h->d_X, h->d_Xc);
+      x_norm = cand_norm;
+      tj = now_s();
+      h->jac_valid = false;
+      rc = ensure_jacobian(h, &o);
+      if (rc) return rc;
+      // StepAccepted
+      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * it.relative_decrease - 1.0, 3));
+      radius = fmin(o.max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      rc = schur_init(h, radius, &o);
+      if (rc) return rc;
+      schur_ready = true;
+      rc = read_scalars(h);
+      if (rc) return rc;
+      t_jac += now_s() - tj;
+      x_cost = h->h_scal[S_COST];
+      it.cost = x_cost;
+      it.gradient_max_norm = fmax(h->h_scal[S_COUNT + S_GMAX_C], h->h_scal[S_COUNT + S_GMAX_P]);
+      it.gradient_norm = sqrt(h->h_scal[S_G2_C] + h->h_scal[S_G2_P]);
+      it.step_is_successful = 1;
+    } else {
+      it.step_is_successful = 0;
+      it.cost = cand_cost;
+      it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
+      radius = radius / decrease_factor;  // StepRejected
+      decrease_factor *= 2.0;
+    }
+    it.iteration_time_in_seconds = now_s() - t_it;
+    it.cumulative_time_in_seconds = now_s() - t_start - t_callbacks;
+  }
+  rc = sync_stream(h);
+  if (rc) return rc;
+  S.num_iterations = S.num_successful_steps + S.num_unsuccessful_steps;
+  S.final_cost = x_cost;
+  S.total_time_in_seconds = now_s() - t_start - t_callbacks;
+  S.linear_solver_time_in_seconds = t_linear;
+  S.jacobian_time_in_seconds = t_jac;
+  S.residual_time_in_seconds = t_res;
+  if (summary) *summary = S;
+  return MIBA_OK;
+}
+
+int miba_get_iterations(miba_handle h, miba_iteration* out, int32_t max, int32_t* n) {
+  if (!h) return fail(h, MIBA_ERR_INVALID, "null handle");
+  if (n) *n = (int32_t)h->iters.size();
+  if (out)
+    for (int32_t i = 0; i < max && i < (int32_t)h->iters.size(); ++i) out[i] = h->iters[i];
+  return MIBA_OK;
+}
+
+int miba_get_kernel_times(miba_handle h, miba_kernel_times* out) {
+  if (!h || !out) return fail(h, MIBA_ERR_INVALID, "null argument");
+  if (h->st) { (void)hipStreamSynchronize(h->st); drain_events(h); }
+  *out = h->kt;
+  out->n_slots = h->n_slots;
+  out->n_obs_local = h->n_obs_local;
+  out->n_pt_local = h->n_pt;
+  out->n_tiles = h->n_tiles;
+  out->n_cam = h->n_cam;
+  return MIBA_OK;
+}
+
+int miba_reset_kernel_times(miba_handle h) {
+  if (!h) return fail(h, MIBA_ERR_INVALID, "null handle");
+  if (h->st) { (void)hipStreamSynchronize(h->st); drain_events(h); }
+  memset(&h->kt, 0, sizeof(h->kt));
+  return MIBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1096 @@
+// miba_kernels.hpp — gfx950 HIP kernels of the LM iteration (SURVEY.md §8a kernel set).
+//
+// Replaces what ceres::Solve (/root/reference/src/BundleAdjustment.cpp:108) does per LM iteration:
+//   K0  k_cam_tables    per-camera rotation tables            (ceres::AngleAxisToRotationMatrix,
+//                                                              src/BAConstraint.cpp:35)
+//   K1  k_eval<true>    residual + analytic Jacobian           (BAConstraint::operator()<Jet>,
+//                                                              src/BAConstraint.cpp:15-80; BAL model :89-128)
+//   K1' k_eval<false>   residual-only cost                     (operator()<double>)
+//   K2  k_schur_init    per-point 3x3 Schur elimination, F'F / rhs / gradient camera sums
+//   K3  k_schur_matvec  implicit Schur complement product  y = S x
+//   K4  k_backsub       back-substitution + model cost change + candidate points
+//   K3v pcg_*           PCG vector kernels with device-resident scalars
+//
+// Layout: observations sorted by point, 256 slots per chunk, a point never straddles a chunk
+// (except a "giant" point that owns its whole tile).  Stored Jacobian J[chunk][26][256]
+// (F row0 0..8, F row1 9..17, E row0 18..20, E row1 21..23, r 24..25): every wave load is a
+// 512-byte contiguous run.  Per-point sums go through an LDS stage and are summed in slot
+// order by one thread per point (deterministic); per-camera sums are accumulated in LDS
+// per tile (ds_add_f64), written as plain rows to a camera-major slab and summed per
+// camera by k_cam_reduce — no global atomics anywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "miba_plan.hpp"
+
+namespace miba {
+
+#define MIBA_DBL_EPS 2.220446049250313e-16
+
+// device-resident PCG / LM control block
+struct Ctl {
+  double rho, rho_prev, pq, alpha, beta, Q0, Q1, zeta, norm_b2;
+  int32_t done;      // 1 => every later PCG kernel returns immediately
+  int32_t status;    // 0 success, 1 no convergence, 2 failure
+  int32_t n_it;      // iterations completed
+  int32_t fail;      // Cholesky failure flags from K2 / cam_blocks
+};
+
+// scalar slots produced by reductions
+enum { S_COST = 0, S_MCC, S_DP2, S_XP2, S_DC2, S_XC2, S_GMAX_C, S_G2_C, S_GMAX_P, S_G2_P, S_COUNT = 16 };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// sum over a 256-thread block; result valid in every thread; s4 = 4 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* s4) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+__device__ __forceinline__ double block_max(double v, double* s4) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(s4[0], s4[1]), fmax(s4[2], s4[3]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: per-camera table  [R 0..8 | t 9..11 | f k1 k2 12..14 | - | dR_0 16..24 | dR_1 25..33 | dR_2 34..42]
+// R row-major; dR_j = dR/dw_j (row-major).  Branches as ceres/rotation.h.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_cam_tables(int n_cam, const double* __restrict__ cam /*[n][9]*/, double* __restrict__ ct) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cam) return;
+  const double* p = cam + 9 * (size_t)c;
+  double* o = ct + (size_t)kCamTabStride * c;
+  const double w0 = p[0], w1 = p[1], w2 = p[2];
+  const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+  double R[9], dR[27];
+  if (th2 > MIBA_DBL_EPS) {
+    const double th = sqrt(th2);
+    const double s = sin(th), c_ = cos(th);
+    const double omc = (c_ > 0.0) ? s * s / (1.0 + c_) : 1.0 - c_;
+    const double k[3] = {w0 / th, w1 / th, w2 / th};
+    R[0] = c_ + k[0] * k[0] * omc;      R[1] = -k[2] * s + k[0] * k[1] * omc; R[2] = k[1] * s + k[0] * k[2] * omc;
+    R[3] = k[2] * s + k[0] * k[1] * omc; R[4] = c_ + k[1] * k[1] * omc;      R[5] = -k[0] * s + k[1] * k[2] * omc;
+    R[6] = -k[1] * s + k[0] * k[2] * omc; R[7] = k[0] * s + k[1] * k[2] * omc; R[8] = c_ + k[2] * k[2] * omc;
+    // dR_j = -s k_j I + c k_j [k]x + s [dk]x + s k_j k k' + omc (dk k' + k dk'),  dk = (e_j - k k_j)/th
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double kj = k[j];
+      double dk[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dk[i] = ((i == j ? 1.0 : 0.0) - k[i] * kj) / th;
+      double* D = dR + 9 * j;
+      const double a = c_ * kj;  // coefficient of [k]x
+      // symmetric part
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          D[r * 3 + q] = (r == q ? -s * kj : 0.0) + s * kj * k[r] * k[q] + omc * (dk[r] * k[q] + k[r] * dk[q]);
+      // skew parts: a [k]x + s [dk]x
+      const double v0 = a * k[0] + s * dk[0], v1 = a * k[1] + s * dk[1], v2 = a * k[2] + s * dk[2];
+      D[1] += -v2; D[2] += v1;
+      D[3] += v2;  D[5] += -v0;
+      D[6] += -v1; D[7] += v0;
+    }
+  } else {
+    R[0] = 1.0; R[1] = -w2; R[2] = w1;
+    R[3] = w2;  R[4] = 1.0; R[5] = -w0;
+    R[6] = -w1; R[7] = w0;  R[8] = 1.0;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) dR[i] = 0.0;
+    // dR_j = [e_j]x
+    dR[0 * 9 + 5] = -1.0; dR[0 * 9 + 7] = 1.0;
+    dR[1 * 9 + 2] = 1.0;  dR[1 * 9 + 6] = -1.0;
+    dR[2 * 9 + 1] = -1.0; dR[2 * 9 + 3] = 1.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o[i] = R[i];
+  o[9] = p[3]; o[10] = p[4]; o[11] = p[5];
+  o[12] = p[6]; o[13] = p[7]; o[14] = p[8];
+  o[15] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 27; ++i) o[16 + i] = dR[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 / K1': residual (+ Jacobian) per observation slot.  One block per tile.
+// ---------------------------------------------------------------------------------------------
+template <bool WITH_JAC>
+__global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, const Group* __restrict__ grps,
+                                              const int32_t* __restrict__ idx, const int32_t* __restrict__ ocam,
+                                              const double* __restrict__ oxy /*[chunk][2][256]*/,
+                                              const double* __restrict__ ct, const double* __restrict__ X /*[npt][3]*/,
+                                              const double* __restrict__ sc /*[ncam][9] or null*/,
+                                              const double* __restrict__ sp /*[npt][3] or null*/,
+                                              double* __restrict__ J, double* __restrict__ partial_cost) {
+  __shared__ double s4[4];
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  for (int g = 0; g < t.ngrp; ++g) {
+    const Group G = grps[t.grp0 + g];
+    for (int ch = 0; ch < G.nchunk; ++ch) {
+      const size_t chunk = (size_t)(G.chunk0 + ch);
+      const size_t slot = chunk * kChunk + tid;
+      const int32_t w = idx[slot];
+      double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+      if (w < 0) {
+        if (WITH_JAC) {
+#pragma unroll
+          for (int k = 0; k < kJComp; ++k) Jc[(size_t)k * kChunk] = 0.0;
+        }
+        continue;
+      }
+      const int cam = ocam[slot];
+      const int p = G.pt0 + (w & 0xFF);
+      const double* T = ct + (size_t)kCamTabStride * cam;
+      const double x0 = X[3 * (size_t)p], x1 = X[3 * (size_t)p + 1], x2 = X[3 * (size_t)p + 2];
+      double R[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = T[i];
+      const double P0 = R[0] * x0 + R[1] * x1 + R[2] * x2 + T[9];
+      const double P1 = R[3] * x0 + R[4] * x1 + R[5] * x2 + T[10];
+      const double P2 = R[6] * x0 + R[7] * x1 + R[8] * x2 + T[11];
+      const double f = T[12], k1 = T[13], k2 = T[14];
+      const double iz = 1.0 / P2;
+      const double px = -P0 * iz, py = -P1 * iz;
+      const double n = px * px + py * py;
+      const double d = 1.0 + n * (k1 + k2 * n);
+      const double ox = oxy[chunk * (2 * kChunk) + tid], oy = oxy[chunk * (2 * kChunk) + kChunk + tid];
+      const double r0 = f * d * px - ox, r1 = f * d * py - oy;
+      acc += r0 * r0 + r1 * r1;
+      if (!WITH_JAC) continue;
+      const double gg = k1 + 2.0 * k2 * n;
+      const double m00 = f * (d + 2.0 * gg * px * px), m01 = f * (2.0 * gg * px * py), m11 = f * (d + 2.0 * gg * py * py);
+      // A = M * dp/dP,  dp/dP = [-iz 0 P0 iz^2; 0 -iz P1 iz^2]
+      const double q0 = P0 * iz * iz, q1 = P1 * iz * iz;
+      double A[6];
+      A[0] = -m00 * iz; A[1] = -m01 * iz; A[2] = m00 * q0 + m01 * q1;
+      A[3] = -m01 * iz; A[4] = -m11 * iz; A[5] = m01 * q0 + m11 * q1;
+      double Fv[18], Ev[6];
+      // rotation columns: A * (dR_j X)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double* D = T + 16 + 9 * j;
+        const double v0 = D[0] * x0 + D[1] * x1 + D[2] * x2;
+        const double v1 = D[3] * x0 + D[4] * x1 + D[5] * x2;
+        const double v2 = D[6] * x0 + D[7] * x1 + D[8] * x2;
+        Fv[j] = A[0] * v0 + A[1] * v1 + A[2] * v2;
+        Fv[9 + j] = A[3] * v0 + A[4] * v1 + A[5] * v2;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { Fv[3 + j] = A[j]; Fv[12 + j] = A[3 + j]; }
+      Fv[6] = d * px;         Fv[15] = d * py;
+      Fv[7] = f * n * px;     Fv[16] = f * n * py;
+      Fv[8] = f * n * n * px; Fv[17] = f * n * n * py;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Ev[j] = A[0] * R[j] + A[1] * R[3 + j] + A[2] * R[6 + j];
+        Ev[3 + j] = A[3] * R[j] + A[4] * R[3 + j] + A[5] * R[6 + j];
+      }
+      if (sc) {
+        const double* s = sc + 9 * (size_t)cam;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const double v = s[k]; Fv[k] *= v; Fv[9 + k] *= v; }
+      }
+      if (sp) {
+        const double* s = sp + 3 * (size_t)p;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double v = s[k]; Ev[k] *= v; Ev[3 + k] *= v; }
+      }
+#pragma unroll
+      for (int k = 0; k < 18; ++k) Jc[(size_t)k * kChunk] = Fv[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jc[(size_t)(18 + k) * kChunk] = Ev[k];
+      Jc[(size_t)24 * kChunk] = r0;
+      Jc[(size_t)25 * kChunk] = r1;
+    }
+  }
+  const double tot = block_sum(acc, s4);
+  if (tid == 0) partial_cost[blockIdx.x] = 0.5 * tot;
+}
+
+// 3x3 SPD inverse through Cholesky (Eigen llt().solve(I) in Ceres). a = {a00,a10,a11,a20,a21,a22}.
+// Returns false if not positive definite.
+__device__ __forceinline__ bool spd3_inverse(const double* a, double* ci /*c00,c10,c11,c20,c21,c22*/) {
+  const double d0 = a[0];
+  if (!(d0 > 0.0)) return false;
+  const double l00 = sqrt(d0);
+  const double l10 = a[1] / l00, l20 = a[3] / l00;
+  const double d1 = a[2] - l10 * l10;
+  if (!(d1 > 0.0)) return false;
+  const double l11 = sqrt(d1);
+  const double l21 = (a[4] - l20 * l10) / l11;
+  const double d2 = a[5] - l20 * l20 - l21 * l21;
+  if (!(d2 > 0.0)) return false;
+  const double l22 = sqrt(d2);
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  ci[0] = i00 * i00 + i10 * i10 + i20 * i20;
+  ci[1] = i10 * i11 + i20 * i21;
+  ci[2] = i11 * i11 + i21 * i21;
+  ci[3] = i20 * i22;
+  ci[4] = i21 * i22;
+  ci[5] = i22 * i22;
+  return true;
+}
+
+__device__ __forceinline__ void load_FE(const double* __restrict__ Jc, double* F, double* E) {
+#pragma unroll
+  for (int k = 0; k < 18; ++k) F[k] = Jc[(size_t)k * kChunk];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) E[k] = Jc[(size_t)(18 + k) * kChunk];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: Schur init.  Per point: C = E'E + Dp^2 -> C^-1, g = E'r, diag(E'E); per camera slab row
+// (64 doubles): upper triangle of F'F (45), F'(r - E C^-1 g) (9), F'r (9).
+// inv_radius: D^2 = clamp(diag, dmin, dmax) * inv_radius.
+// ---------------------------------------------------------------------------------------------
+constexpr int kK2W = 64;
+__global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ tiles, const Group* __restrict__ grps,
+                                                    const int32_t* __restrict__ idx, const int2* __restrict__ pt_rng,
+                                                    const int32_t* __restrict__ slab_row, const double* __restrict__ J,
+                                                    double inv_radius, double dmin, double dmax,
+                                                    double* __restrict__ Cinv /*[npt][6]*/, double* __restrict__ gp /*[npt][3]*/,
+                                                    double* __restrict__ dgp /*[npt][3] diag E'E*/,
+                                                    double* __restrict__ slab /*[nrows][64]*/, Ctl* __restrict__ ctl) {
+  extern __shared__ double lds[];
+  double* s_acc = lds;                              // [kMaxCamSlots][63]  (stride 63: odd => fewer bank conflicts)
+  double* s_stage = lds + kMaxCamSlots * 63;        // [256][9]
+  double* s_y = s_stage + kChunk * 9;               // [256][3]
+  double* s4 = s_y + kChunk * 3;                    // [4]
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (!t.giant)
+    for (int i = tid; i < t.ncs * 63; i += kChunk) s_acc[i] = 0.0;
+  __syncthreads();
+  for (int g = 0; g < t.ngrp; ++g) {
+    const Group G = grps[t.grp0 + g];
+    if (G.nchunk == 1) {
+      const size_t chunk = (size_t)G.chunk0;
+      const size_t slot = chunk * kChunk + tid;
+      const int32_t w = idx[slot];
+      const bool valid = w >= 0;
+      const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+      double F[18], E[6], r0 = 0.0, r1 = 0.0;
+      if (valid) {
+        load_FE(Jc, F, E);
+        r0 = Jc[(size_t)24 * kChunk]; r1 = Jc[(size_t)25 * kChunk];
+        double* st = s_stage + tid * 9;
+        st[0] = E[0] * E[0] + E[3] * E[3];
+        st[1] = E[1] * E[0] + E[4] * E[3];
+        st[2] = E[1] * E[1] + E[4] * E[4];
+        st[3] = E[2] * E[0] + E[5] * E[3];
+        st[4] = E[2] * E[1] + E[5] * E[4];
+        st[5] = E[2] * E[2] + E[5] * E[5];
+        st[6] = E[0] * r0 + E[3] * r1;
+        st[7] = E[1] * r0 + E[4] * r1;
+        st[8] = E[2] * r0 + E[5] * r1;
+      }
+      __syncthreads();
+      if (tid < G.npt) {
+        const int p = G.pt0 + tid;
+        const int2 rg = pt_rng[p];
+        const int l0 = rg.x - (int)(chunk * kChunk);
+        double a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] = 0.0;
+        for (int l = l0; l < l0 + rg.y; ++l) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) a[k] += s_stage[l * 9 + k];
+        }
+        dgp[3 * (size_t)p] = a[0]; dgp[3 * (size_t)p + 1] = a[2]; dgp[3 * (size_t)p + 2] = a[5];
+        double c[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
+        c[0] += fmin(fmax(a[0], dmin), dmax) * inv_radius;
+        c[2] += fmin(fmax(a[2], dmin), dmax) * inv_radius;
+        c[5] += fmin(fmax(a[5], dmin), dmax) * inv_radius;
+        double ci[6];
+        if (!spd3_inverse(c, ci)) {
+          ctl->fail = 1;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ci[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Cinv[6 * (size_t)p + k] = ci[k];
+        gp[3 * (size_t)p] = a[6]; gp[3 * (size_t)p + 1] = a[7]; gp[3 * (size_t)p + 2] = a[8];
+        s_y[tid * 3 + 0] = ci[0] * a[6] + ci[1] * a[7] + ci[3] * a[8];
+        s_y[tid * 3 + 1] = ci[1] * a[6] + ci[2] * a[7] + ci[4] * a[8];
+        s_y[tid * 3 + 2] = ci[3] * a[6] + ci[4] * a[7] + ci[5] * a[8];
+      }
+      __syncthreads();
+      if (valid) {
+        const int pl = w & 0xFF;
+        const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
+        const double v0 = r0 - (E[0] * y0 + E[1] * y1 + E[2] * y2);
+        const double v1 = r1 - (E[3] * y0 + E[4] * y1 + E[5] * y2);
+        double* dst;
+        if (t.giant) dst = slab + (size_t)kK2W * slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
+        else dst = s_acc + 63 * ((w >> 8) & 0xFF);
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+          for (int j = i; j < 9; ++j) {
+            const double v = F[i] * F[j] + F[9 + i] * F[9 + j];
+            if (t.giant) dst[o] = v; else atomicAdd(dst + o, v);
+            ++o;
+          }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double v = F[k] * v0 + F[9 + k] * v1;
+          const double u = F[k] * r0 + F[9 + k] * r1;
+          if (t.giant) { dst[45 + k] = v; dst[54 + k] = u; }
+          else { atomicAdd(dst + 45 + k, v); atomicAdd(dst + 54 + k, u); }
+        }
+        if (t.giant) dst[63] = 0.0;
+      }
+    } else {
+      // giant point spanning several chunks: block-wide sums, two passes over its chunks
+      const int p = G.pt0;
+      double a[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a[k] = 0.0;
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        const bool valid = idx[slot] >= 0;
+        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = 0.0;
+        if (valid) {
+          double E[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) E[k] = Jc[(size_t)(18 + k) * kChunk];
+          const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
+          v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[1] * E[0] + E[4] * E[3]; v[2] = E[1] * E[1] + E[4] * E[4];
+          v[3] = E[2] * E[0] + E[5] * E[3]; v[4] = E[2] * E[1] + E[5] * E[4]; v[5] = E[2] * E[2] + E[5] * E[5];
+          v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] += block_sum(v[k], s4);
+      }
+      double c[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
+      c[0] += fmin(fmax(a[0], dmin), dmax) * inv_radius;
+      c[2] += fmin(fmax(a[2], dmin), dmax) * inv_radius;
+      c[5] += fmin(fmax(a[5], dmin), dmax) * inv_radius;
+      double ci[6];
+      if (!spd3_inverse(c, ci)) {
+        if (tid == 0) ctl->fail = 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ci[k] = 0.0;
+      }
+      if (tid == 0) {
+        dgp[3 * (size_t)p] = a[0]; dgp[3 * (size_t)p + 1] = a[2]; dgp[3 * (size_t)p + 2] = a[5];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Cinv[6 * (size_t)p + k] = ci[k];
+        gp[3 * (size_t)p] = a[6]; gp[3 * (size_t)p + 1] = a[7]; gp[3 * (size_t)p + 2] = a[8];
+      }
+      const double y0 = ci[0] * a[6] + ci[1] * a[7] + ci[3] * a[8];
+      const double y1 = ci[1] * a[6] + ci[2] * a[7] + ci[4] * a[8];
+      const double y2 = ci[3] * a[6] + ci[4] * a[7] + ci[5] * a[8];
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        if (idx[slot] < 0) continue;
+        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+        double F[18], E[6];
+        load_FE(Jc, F, E);
+        const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
+        const double v0 = r0 - (E[0] * y0 + E[1] * y1 + E[2] * y2);
+        const double v1 = r1 - (E[3] * y0 + E[4] * y1 + E[5] * y2);
+        double* dst = slab + (size_t)kK2W * slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+          for (int j = i; j < 9; ++j) dst[o++] = F[i] * F[j] + F[9 + i] * F[9 + j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          dst[45 + k] = F[k] * v0 + F[9 + k] * v1;
+          dst[54 + k] = F[k] * r0 + F[9 + k] * r1;
+        }
+        dst[63] = 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  if (!t.giant) {
+    for (int i = tid; i < t.ncs * kK2W; i += kChunk) {
+      const int s = i >> 6, k = i & 63;
+      slab[(size_t)kK2W * slab_row[t.cam0 + s] + k] = (k < 63) ? s_acc[s * 63 + k] : 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: y = S x without the D^2 x term (added by k_cam_reduce9):  per tile
+//   u = F x_c ; y2_p = sum E'u ; y3 = -C^-1 y2 ; w = u + E y3 ; slab row = sum F'w
+// MODE 0: matvec (above).  MODE 1: squared column norms (Jacobi scaling at iteration 0):
+//   slab row = sum F.^2, nrm_p = sum E.^2.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_schur_matvec(const Tile* __restrict__ tiles, const Group* __restrict__ grps,
+                                                      const int32_t* __restrict__ idx, const int2* __restrict__ pt_rng,
+                                                      const int32_t* __restrict__ tile_cams,
+                                                      const int32_t* __restrict__ slab_row, const double* __restrict__ J,
+                                                      const double* __restrict__ Cinv, const double* __restrict__ x,
+                                                      double* __restrict__ slab /*[nrows][9]*/,
+                                                      double* __restrict__ nrm_p /*[npt][3], MODE 1*/,
+                                                      const Ctl* __restrict__ ctl) {
+  __shared__ double s_x[kMaxCamSlots * 9];
+  __shared__ double s_acc[kMaxCamSlots * 9];
+  __shared__ double s_stage[kChunk * 3];
+  __shared__ double s_y[kChunk * 3];
+  __shared__ double s4[4];
+  if (MODE == 0 && ctl->done) return;
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (!t.giant) {
+    for (int i = tid; i < t.ncs * 9; i += kChunk) {
+      if (MODE == 0) s_x[i] = x[9 * (size_t)tile_cams[t.cam0 + i / 9] + i % 9];
+      s_acc[i] = 0.0;
+    }
+  }
+  __syncthreads();
+  for (int g = 0; g < t.ngrp; ++g) {
+    const Group G = grps[t.grp0 + g];
+    if (G.nchunk == 1) {
+      const size_t chunk = (size_t)G.chunk0;
+      const size_t slot = chunk * kChunk + tid;
+      const int32_t w = idx[slot];
+      const bool valid = w >= 0;
+      const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+      double F[18], E[6], u0 = 0.0, u1 = 0.0;
+      const int cs = (w >> 8) & 0xFF;
+      if (valid) {
+        load_FE(Jc, F, E);
+        if (MODE == 0) {
+          const double* xc = t.giant ? (x + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)]) : (s_x + 9 * cs);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { const double xv = xc[k]; u0 += F[k] * xv; u1 += F[9 + k] * xv; }
+          s_stage[tid * 3 + 0] = E[0] * u0 + E[3] * u1;
+          s_stage[tid * 3 + 1] = E[1] * u0 + E[4] * u1;
+          s_stage[tid * 3 + 2] = E[2] * u0 + E[5] * u1;
+        } else {
+          s_stage[tid * 3 + 0] = E[0] * E[0] + E[3] * E[3];
+          s_stage[tid * 3 + 1] = E[1] * E[1] + E[4] * E[4];
+          s_stage[tid * 3 + 2] = E[2] * E[2] + E[5] * E[5];
+        }
+      }
+      __syncthreads();
+      if (tid < G.npt) {
+        const int p = G.pt0 + tid;
+        const int2 rg = pt_rng[p];
+        const int l0 = rg.x - (int)(chunk * kChunk);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int l = l0; l < l0 + rg.y; ++l) { a0 += s_stage[l * 3]; a1 += s_stage[l * 3 + 1]; a2 += s_stage[l * 3 + 2]; }
+        if (MODE == 0) {
+          const double* ci = Cinv + 6 * (size_t)p;
+          s_y[tid * 3 + 0] = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2);
+          s_y[tid * 3 + 1] = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2);
+          s_y[tid * 3 + 2] = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2);
+        } else {
+          nrm_p[3 * (size_t)p] = a0; nrm_p[3 * (size_t)p + 1] = a1; nrm_p[3 * (size_t)p + 2] = a2;
+        }
+      }
+      if (MODE == 0) __syncthreads();
+      if (valid) {
+        double w0 = 0.0, w1 = 0.0;
+        if (MODE == 0) {
+          const int pl = w & 0xFF;
+          const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
+          w0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
+          w1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
+        }
+        if (t.giant) {
+          double* dst = slab + 9 * (size_t)slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) dst[k] = (MODE == 0) ? F[k] * w0 + F[9 + k] * w1 : F[k] * F[k] + F[9 + k] * F[9 + k];
+        } else {
+          double* dst = s_acc + 9 * cs;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) atomicAdd(dst + k, (MODE == 0) ? F[k] * w0 + F[9 + k] * w1 : F[k] * F[k] + F[9 + k] * F[9 + k]);
+        }
+      }
+      __syncthreads();  // s_stage / s_y are reused by the next group
+    } else {
+      const int p = G.pt0;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        if (idx[slot] >= 0) {
+          double F[18], E[6];
+          load_FE(Jc, F, E);
+          if (MODE == 0) {
+            const double* xc = x + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)];
+            double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
+            v0 = E[0] * u0 + E[3] * u1; v1 = E[1] * u0 + E[4] * u1; v2 = E[2] * u0 + E[5] * u1;
+          } else {
+            v0 = E[0] * E[0] + E[3] * E[3]; v1 = E[1] * E[1] + E[4] * E[4]; v2 = E[2] * E[2] + E[5] * E[5];
+          }
+        }
+        a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
+      }
+      double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+      if (MODE == 0) {
+        const double* ci = Cinv + 6 * (size_t)p;
+        y0 = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2);
+        y1 = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2);
+        y2 = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2);
+      } else if (tid == 0) {
+        nrm_p[3 * (size_t)p] = a0; nrm_p[3 * (size_t)p + 1] = a1; nrm_p[3 * (size_t)p + 2] = a2;
+      }
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        if (idx[slot] < 0) continue;
+        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+        double F[18], E[6];
+        load_FE(Jc, F, E);
+        const int pos = (int)(slot - (size_t)t.slot0);
+        double* dst = slab + 9 * (size_t)slab_row[t.cam0 + pos];
+        if (MODE == 0) {
+          const double* xc = x + 9 * (size_t)tile_cams[t.cam0 + pos];
+          double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
+          const double w0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
+          const double w1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) dst[k] = F[k] * w0 + F[9 + k] * w1;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) dst[k] = F[k] * F[k] + F[9 + k] * F[9 + k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!t.giant)
+    for (int i = tid; i < t.ncs * 9; i += kChunk) slab[9 * (size_t)slab_row[t.cam0 + i / 9] + i % 9] = s_acc[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: back-substitution  y_p = C^-1 (g_p - sum E'F y_c), model cost change, candidate points.
+//   partial[4*tile + {0,1,2}] = {sum Jy.(r - Jy/2), |delta_p|^2, |x_cand_p|^2}
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_backsub(const Tile* __restrict__ tiles, const Group* __restrict__ grps,
+                                                 const int32_t* __restrict__ idx, const int2* __restrict__ pt_rng,
+                                                 const int32_t* __restrict__ tile_cams, const double* __restrict__ J,
+                                                 const double* __restrict__ Cinv, const double* __restrict__ gp,
+                                                 const double* __restrict__ yc /*[ncam][9]*/,
+                                                 const double* __restrict__ sp /*[npt][3]*/, const double* __restrict__ X,
+                                                 double* __restrict__ yp /*[npt][3]*/, double* __restrict__ Xc,
+                                                 double* __restrict__ partial) {
+  __shared__ double s_x[kMaxCamSlots * 9];
+  __shared__ double s_stage[kChunk * 3];
+  __shared__ double s_y[kChunk * 3];
+  __shared__ double s4[4];
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (!t.giant)
+    for (int i = tid; i < t.ncs * 9; i += kChunk) s_x[i] = yc[9 * (size_t)tile_cams[t.cam0 + i / 9] + i % 9];
+  __syncthreads();
+  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0;
+  for (int g = 0; g < t.ngrp; ++g) {
+    const Group G = grps[t.grp0 + g];
+    if (G.nchunk == 1) {
+      const size_t chunk = (size_t)G.chunk0;
+      const size_t slot = chunk * kChunk + tid;
+      const int32_t w = idx[slot];
+      const bool valid = w >= 0;
+      const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+      double E[6], u0 = 0.0, u1 = 0.0;
+      if (valid) {
+        double F[18];
+        load_FE(Jc, F, E);
+        const double* xc = t.giant ? (yc + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)]) : (s_x + 9 * ((w >> 8) & 0xFF));
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const double xv = xc[k]; u0 += F[k] * xv; u1 += F[9 + k] * xv; }
+        s_stage[tid * 3 + 0] = E[0] * u0 + E[3] * u1;
+        s_stage[tid * 3 + 1] = E[1] * u0 + E[4] * u1;
+        s_stage[tid * 3 + 2] = E[2] * u0 + E[5] * u1;
+      }
+      __syncthreads();
+      if (tid < G.npt) {
+        const int p = G.pt0 + tid;
+        const int2 rg = pt_rng[p];
+        const int l0 = rg.x - (int)(chunk * kChunk);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int l = l0; l < l0 + rg.y; ++l) { a0 += s_stage[l * 3]; a1 += s_stage[l * 3 + 1]; a2 += s_stage[l * 3 + 2]; }
+        const double* ci = Cinv + 6 * (size_t)p;
+        const double b0 = gp[3 * (size_t)p] - a0, b1 = gp[3 * (size_t)p + 1] - a1, b2 = gp[3 * (size_t)p + 2] - a2;
+        const double y0 = ci[0] * b0 + ci[1] * b1 + ci[3] * b2;
+        const double y1 = ci[1] * b0 + ci[2] * b1 + ci[4] * b2;
+        const double y2 = ci[3] * b0 + ci[4] * b1 + ci[5] * b2;
+        s_y[tid * 3] = y0; s_y[tid * 3 + 1] = y1; s_y[tid * 3 + 2] = y2;
+        yp[3 * (size_t)p] = y0; yp[3 * (size_t)p + 1] = y1; yp[3 * (size_t)p + 2] = y2;
+        const double d0 = -y0 * sp[3 * (size_t)p], d1 = -y1 * sp[3 * (size_t)p + 1], d2 = -y2 * sp[3 * (size_t)p + 2];
+        const double c0 = X[3 * (size_t)p] + d0, c1 = X[3 * (size_t)p + 1] + d1, c2 = X[3 * (size_t)p + 2] + d2;
+        Xc[3 * (size_t)p] = c0; Xc[3 * (size_t)p + 1] = c1; Xc[3 * (size_t)p + 2] = c2;
+        // step norm exactly as Ceres: |x - x_cand|
+        const double e0 = X[3 * (size_t)p] - c0, e1 = X[3 * (size_t)p + 1] - c1, e2 = X[3 * (size_t)p + 2] - c2;
+        dp2 += e0 * e0 + e1 * e1 + e2 * e2;
+        xp2 += c0 * c0 + c1 * c1 + c2 * c2;
+      }
+      __syncthreads();
+      if (valid) {
+        const int pl = w & 0xFF;
+        const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
+        const double m0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
+        const double m1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
+        const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
+        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
+      }
+      __syncthreads();
+    } else {
+      const int p = G.pt0;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        if (idx[slot] >= 0) {
+          double F[18], E[6];
+          load_FE(Jc, F, E);
+          const double* xc = yc + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)];
+          double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
+          v0 = E[0] * u0 + E[3] * u1; v1 = E[1] * u0 + E[4] * u1; v2 = E[2] * u0 + E[5] * u1;
+        }
+        a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
+      }
+      const double* ci = Cinv + 6 * (size_t)p;
+      const double b0 = gp[3 * (size_t)p] - a0, b1 = gp[3 * (size_t)p + 1] - a1, b2 = gp[3 * (size_t)p + 2] - a2;
+      const double y0 = ci[0] * b0 + ci[1] * b1 + ci[3] * b2;
+      const double y1 = ci[1] * b0 + ci[2] * b1 + ci[4] * b2;
+      const double y2 = ci[3] * b0 + ci[4] * b1 + ci[5] * b2;
+      if (tid == 0) {
+        yp[3 * (size_t)p] = y0; yp[3 * (size_t)p + 1] = y1; yp[3 * (size_t)p + 2] = y2;
+        const double c0 = X[3 * (size_t)p] - y0 * sp[3 * (size_t)p], c1 = X[3 * (size_t)p + 1] - y1 * sp[3 * (size_t)p + 1],
+                     c2 = X[3 * (size_t)p + 2] - y2 * sp[3 * (size_t)p + 2];
+        Xc[3 * (size_t)p] = c0; Xc[3 * (size_t)p + 1] = c1; Xc[3 * (size_t)p + 2] = c2;
+        const double e0 = X[3 * (size_t)p] - c0, e1 = X[3 * (size_t)p + 1] - c1, e2 = X[3 * (size_t)p + 2] - c2;
+        dp2 += e0 * e0 + e1 * e1 + e2 * e2;
+        xp2 += c0 * c0 + c1 * c1 + c2 * c2;
+      }
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        if (idx[slot] < 0) continue;
+        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
+        double F[18], E[6];
+        load_FE(Jc, F, E);
+        const double* xc = yc + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)];
+        double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
+        const double m0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
+        const double m1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
+        const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
+        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
+      }
+    }
+  }
+  const double s0 = block_sum(mcc, s4);
+  const double s1 = block_sum(dp2, s4);
+  const double s2 = block_sum(xp2, s4);
+  if (tid == 0) {
+    partial[4 * (size_t)blockIdx.x + 0] = s0;
+    partial[4 * (size_t)blockIdx.x + 1] = s1;
+    partial[4 * (size_t)blockIdx.x + 2] = s2;
+    partial[4 * (size_t)blockIdx.x + 3] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera-major slab reductions (deterministic: rows are summed in row order per camera).
+// One wave per camera.  cam_row_off[c]..cam_row_off[c+1] = rows of camera c on this shard.
+// ---------------------------------------------------------------------------------------------
+// W = 9:  out[c][k] = diag_w * d2[c][k] * x[c][k] + sum rows      (d2 may be null)
+__global__ __launch_bounds__(256) void k_cam_reduce9(int n_cam, const int32_t* __restrict__ cam_row_off,
+                                                     const double* __restrict__ slab, const double* __restrict__ d2,
+                                                     const double* __restrict__ x, double diag_w,
+                                                     double* __restrict__ out, const Ctl* __restrict__ ctl) {
+  if (ctl && ctl->done) return;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_cam) return;
+  const int lane = threadIdx.x & 63;
+  const int r0 = cam_row_off[c], r1 = cam_row_off[c + 1];
+  const int sub = lane / 9, k = lane % 9;  // 7 row lanes x 9 components (lane 63 idle)
+  double acc = 0.0;
+  if (lane < 63)
+    for (int r = r0 + sub; r < r1; r += 7) acc += slab[9 * (size_t)r + k];
+  // combine the 7 sub-rows in fixed order: lanes k, k+9, ..., k+54
+  double tot = acc;
+#pragma unroll
+  for (int s = 1; s < 7; ++s) tot += __shfl(acc, k + 9 * s, 64);
+  if (lane < 9) {
+    double v = tot;
+    if (d2) v += diag_w * d2[9 * (size_t)c + k] * x[9 * (size_t)c + k];
+    out[9 * (size_t)c + k] = v;
+  }
+}
+
+// W = 64: out[c][0..63] = sum rows (lane = component)
+__global__ __launch_bounds__(256) void k_cam_reduce64(int n_cam, const int32_t* __restrict__ cam_row_off,
+                                                      const double* __restrict__ slab, double* __restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_cam) return;
+  const int lane = threadIdx.x & 63;
+  double a0 = 0.0;
+  for (int r = cam_row_off[c]; r < cam_row_off[c + 1]; ++r) a0 += slab[(size_t)kK2W * r + lane];
+  out[(size_t)kK2W * c + lane] = a0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera blocks: B = F'F + D^2 -> M^-1 (9x9 Cholesky inverse), rhs, unscaled gradient norms.
+// acc[c][64] = {F'F upper 45, rhs 9, F'r 9}.  One thread per camera.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const uint8_t* __restrict__ active,
+                             const double* __restrict__ sc, double inv_radius, double dmin, double dmax,
+                             double* __restrict__ Minv /*[n][81]*/, double* __restrict__ Dc2 /*[n][9]*/,
+                             double* __restrict__ rhs /*[n][9]*/, double* __restrict__ partial /*[nblk][2]*/,
+                             Ctl* __restrict__ ctl) {
+  __shared__ double s4[4];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  double gmax = 0.0, g2 = 0.0;
+  if (c < n_cam) {
+    const double* a = acc + (size_t)kK2W * c;
+    double L[81];
+    int o = 0;
+    for (int i = 0; i < 9; ++i)
+      for (int j = i; j < 9; ++j) { L[j * 9 + i] = a[o]; L[i * 9 + j] = a[o]; ++o; }
+    for (int i = 0; i < 9; ++i) {
+      const double d2 = fmin(fmax(L[i * 9 + i], dmin), dmax) * inv_radius;
+      Dc2[9 * (size_t)c + i] = d2;
+      L[i * 9 + i] += d2;
+      rhs[9 * (size_t)c + i] = a[45 + i];
+      if (active[c]) {
+        const double gu = a[54 + i] / sc[9 * (size_t)c + i];  // gradient of the unscaled problem
+        gmax = fmax(gmax, fabs(gu));
+        g2 += gu * gu;
+      }
+    }
+    // in-place lower Cholesky
+    bool ok = true;
+    for (int j = 0; j < 9 && ok; ++j) {
+      double d = L[j * 9 + j];
+      for (int k = 0; k < j; ++k) d -= L[j * 9 + k] * L[j * 9 + k];
+      if (!(d > 0.0)) { ok = false; break; }
+      d = sqrt(d);
+      L[j * 9 + j] = d;
+      for (int i = j + 1; i < 9; ++i) {
+        double s = L[i * 9 + j];
+        for (int k = 0; k < j; ++k) s -= L[i * 9 + k] * L[j * 9 + k];
+        L[i * 9 + j] = s / d;
+      }
+    }
+    double* Mi = Minv + 81 * (size_t)c;
+    if (!ok) {
+      ctl->fail = 1;
+      for (int i = 0; i < 81; ++i) Mi[i] = 0.0;
+    } else {
+      // solve L L' col = e_j for each j
+      for (int j = 0; j < 9; ++j) {
+        double col[9];
+        for (int i = 0; i < 9; ++i) {
+          double s = (i == j) ? 1.0 : 0.0;
+          for (int k = 0; k < i; ++k) s -= L[i * 9 + k] * col[k];
+          col[i] = s / L[i * 9 + i];
+        }
+        for (int i = 8; i >= 0; --i) {
+          double s = col[i];
+          for (int k = i + 1; k < 9; ++k) s -= L[k * 9 + i] * col[k];
+          col[i] = s / L[i * 9 + i];
+        }
+        for (int i = 0; i < 9; ++i) Mi[i * 9 + j] = col[i];
+      }
+    }
+  }
+  const double m = block_max(gmax, s4);
+  const double s = block_sum(g2, s4);
+  if (threadIdx.x == 0) { partial[2 * (size_t)blockIdx.x] = m; partial[2 * (size_t)blockIdx.x + 1] = s; }
+}
+
+// point gradient norms (unscaled): g_p / sp
+__global__ __launch_bounds__(256) void k_pt_gradnorm(int n_pt, const double* __restrict__ gp, const double* __restrict__ sp,
+                                                     double* __restrict__ partial /*[nblk][2]*/) {
+  __shared__ double s4[4];
+  double gmax = 0.0, g2 = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * (size_t)n_pt; i += (size_t)gridDim.x * blockDim.x) {
+    const double g = gp[i] / sp[i];
+    gmax = fmax(gmax, fabs(g));
+    g2 += g * g;
+  }
+  const double m = block_max(gmax, s4);
+  const double s = block_sum(g2, s4);
+  if (threadIdx.x == 0) { partial[2 * (size_t)blockIdx.x] = m; partial[2 * (size_t)blockIdx.x + 1] = s; }
+}
+
+// out[slot] = sum (or max) over n entries of partial[i*stride + off]; single 1024-thread block.
+__global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ partial, size_t n, int stride, int off,
+                                                 int is_max, double* __restrict__ out) {
+  __shared__ double s[16];
+  double v = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const double x = partial[i * stride + off];
+    v = is_max ? fmax(v, x) : v + x;
+  }
+  v = is_max ? wave_max(v) : wave_sum(v);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = s[0];
+    for (int i = 1; i < 16; ++i) t = is_max ? fmax(t, s[i]) : t + s[i];
+    *out = t;
+  }
+}
+
+// scale = 1/(1+sqrt(n2)); inactive entries -> 1
+__global__ void k_make_scale(size_t n, const double* __restrict__ n2, double* __restrict__ scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scale[i] = 1.0 / (1.0 + sqrt(n2[i]));
+}
+__global__ void k_fill(size_t n, double v, double* __restrict__ a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+// candidate cameras: cand = cam - sc .* yc ; partial {|cam-cand|^2, |cand|^2} over active cameras
+__global__ __launch_bounds__(256) void k_cam_update(int n_cam, const double* __restrict__ cam, const double* __restrict__ sc,
+                                                    const double* __restrict__ yc, const uint8_t* __restrict__ active,
+                                                    double* __restrict__ cand, double* __restrict__ partial) {
+  __shared__ double s4[4];
+  double d2 = 0.0, x2 = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 9 * (size_t)n_cam; i += (size_t)gridDim.x * blockDim.x) {
+    const double c = cam[i] - yc[i] * sc[i];
+    cand[i] = c;
+    if (active[i / 9]) {
+      const double e = cam[i] - c;
+      d2 += e * e;
+      x2 += c * c;
+    }
+  }
+  const double a = block_sum(d2, s4);
+  const double b = block_sum(x2, s4);
+  if (threadIdx.x == 0) { partial[2 * (size_t)blockIdx.x] = a; partial[2 * (size_t)blockIdx.x + 1] = b; }
+}
+
+// sum of squares of active entries (|x|^2 at start): stride = entries per block (9 cams / 3 pts)
+__global__ __launch_bounds__(256) void k_sumsq(size_t n, const double* __restrict__ a, const uint8_t* __restrict__ active, int per,
+                                               double* __restrict__ partial) {
+  __shared__ double s4[4];
+  double x2 = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (!active || active[i / per]) x2 += a[i] * a[i];
+  const double s = block_sum(x2, s4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCG vector kernels (ConjugateGradientsSolver).  Fixed grid of kPcgBlocks
+// blocks, grid-stride; dot products leave one partial per block which the consumer kernels
+// sum in block order (deterministic, and identical on every rank).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPcgBlocks = 120;
+
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, double* s4) {
+  const double v = (threadIdx.x < kPcgBlocks) ? part[threadIdx.x] : 0.0;
+  return block_sum(v, s4);
+}
+
+// start: x = 0, r = b, ctl reset; partial norm_b2
+__global__ __launch_bounds__(256) void pcg_start(size_t n, const double* __restrict__ b, double* __restrict__ x,
+                                                 double* __restrict__ r, Ctl* __restrict__ ctl, double* __restrict__ part) {
+  __shared__ double s4[4];
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double v = b[i];
+    x[i] = 0.0;
+    r[i] = v;
+    acc += v * v;
+  }
+  const double s = block_sum(acc, s4);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->rho = 1.0; ctl->rho_prev = 1.0; ctl->Q0 = 0.0; ctl->Q1 = 0.0; ctl->zeta = 0.0;
+    ctl->pq = 0.0; ctl->alpha = 0.0; ctl->beta = 0.0;
+    ctl->done = 0; ctl->status = 1; ctl->n_it = 0;
+  }
+}
+// finish start: norm_b == 0 => done (success)
+__global__ void pcg_start2(const double* __restrict__ part, Ctl* __restrict__ ctl) {
+  __shared__ double s4[4];
+  const double nb2 = sum_partials(part, s4);
+  if (threadIdx.x == 0) {
+    ctl->norm_b2 = nb2;
+    if (nb2 == 0.0) { ctl->done = 1; ctl->status = 0; }
+  }
+}
+// z = M^-1 r (9x9 blocks); partial rho = r.z.  One thread per vector entry.
+__global__ __launch_bounds__(256) void pcg_precond(size_t n, const double* __restrict__ Minv, const double* __restrict__ r,
+                                                   double* __restrict__ z, const Ctl* __restrict__ ctl, double* __restrict__ part) {
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = i / 9;
+    const double* m = Minv + 9 * i;  // row (i%9) of block c = Minv[c*81 + (i%9)*9]
+    const double* rc = r + 9 * c;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s += m[j] * rc[j];
+    z[i] = s;
+    acc += r[i] * s;
+  }
+  const double s = block_sum(acc, s4);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// rho, beta; p = z + beta p
+__global__ __launch_bounds__(256) void pcg_dir(size_t n, const double* __restrict__ z, double* __restrict__ p, Ctl* __restrict__ ctl,
+                                               const double* __restrict__ part) {
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  const double rho = sum_partials(part, s4);
+  const double last_rho = ctl->rho;     // written by the previous iteration's pcg_dir
+  const int it = ctl->n_it + 1;
+  bool bad = (rho == 0.0) || isinf(rho) || isnan(rho);
+  double beta = 0.0;
+  if (!bad && it > 1) {
+    beta = rho / last_rho;
+    bad = (beta == 0.0) || isinf(beta) || isnan(beta);
+  }
+  __syncthreads();  // every thread has read ctl before block 0 updates it
+  if (!bad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+      p[i] = (it == 1) ? z[i] : z[i] + beta * p[i];
+  }
+  // ctl is only written by the LAST block to finish reading it: use a separate tail kernel instead
+}
+// tail of pcg_dir: commit rho / failure (single thread; runs after every block of pcg_dir read ctl)
+__global__ void pcg_dir_commit(Ctl* __restrict__ ctl, const double* __restrict__ part) {
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  const double rho = sum_partials(part, s4);
+  if (threadIdx.x == 0) {
+    const int it = ctl->n_it + 1;
+    bool bad = (rho == 0.0) || isinf(rho) || isnan(rho);
+    double beta = 0.0;
+    if (!bad && it > 1) {
+      beta = rho / ctl->rho;
+      bad = (beta == 0.0) || isinf(beta) || isnan(beta);
+    }
+    ctl->rho_prev = ctl->rho;
+    ctl->rho = rho;
+    ctl->beta = beta;
+    if (bad) { ctl->done = 1; ctl->status = 2; ctl->n_it = it; }
+  }
+}
+// partial p.q
+__global__ __launch_bounds__(256) void pcg_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                               const Ctl* __restrict__ ctl, double* __restrict__ part) {
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += a[i] * b[i];
+  const double s = block_sum(acc, s4);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// alpha = rho / pq ; x += alpha p ; (reset == 0) r -= alpha q ; partial Q = x.(b + r)
+// reset == 1: only x is updated here (r is rebuilt by pcg_resid after an extra mat-vec).
+__global__ __launch_bounds__(256) void pcg_update(size_t n, const double* __restrict__ p, const double* __restrict__ q,
+                                                  const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
+                                                  const Ctl* __restrict__ ctl, const double* __restrict__ part_pq,
+                                                  double* __restrict__ part_q, int reset) {
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  const double pq = sum_partials(part_pq, s4);
+  if (pq <= 0.0 || isinf(pq) || isnan(pq)) return;  // committed by pcg_update_commit
+  const double alpha = ctl->rho / pq;
+  if (isinf(alpha)) return;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double xv = x[i] + alpha * p[i];
+    x[i] = xv;
+    if (!reset) {
+      const double rv = r[i] - alpha * q[i];
+      r[i] = rv;
+      acc += xv * (b[i] + rv);
+    }
+  }
+  if (!reset) {
+    const double s = block_sum(acc, s4);
+    if (threadIdx.x == 0) part_q[blockIdx.x] = s;
+  }
+}
+// r = b - Sx ; partial Q
+__global__ __launch_bounds__(256) void pcg_resid(size_t n, const double* __restrict__ b, const double* __restrict__ Sx,
+                                                 const double* __restrict__ x, double* __restrict__ r, const Ctl* __restrict__ ctl,
+                                                 const double* __restrict__ part_pq, double* __restrict__ part_q) {
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  const double pq = sum_partials(part_pq, s4);
+  if (pq <= 0.0 || isinf(pq) || isnan(pq) || isinf(ctl->rho / pq)) return;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double rv = b[i] - Sx[i];
+    r[i] = rv;
+    acc += x[i] * (b[i] + rv);
+  }
+  const double s = block_sum(acc, s4);
+  if (threadIdx.x == 0) part_q[blockIdx.x] = s;
+}
+// end of iteration: pq / alpha checks, Q-tolerance test, iteration counter (single block)
+__global__ void pcg_check(Ctl* __restrict__ ctl, const double* __restrict__ part_pq, const double* __restrict__ part_q,
+                          double q_tol, int min_it, int max_it) {
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  const double pq = sum_partials(part_pq, s4);
+  const double qs = sum_partials(part_q, s4);
+  if (threadIdx.x == 0) {
+    const int it = ctl->n_it + 1;
+    ctl->n_it = it;
+    ctl->pq = pq;
+    if (pq <= 0.0 || isinf(pq) || isnan(pq)) { ctl->done = 1; ctl->status = 1; return; }
+    const double alpha = ctl->rho / pq;
+    ctl->alpha = alpha;
+    if (isinf(alpha)) { ctl->done = 1; ctl->status = 2; return; }
+    const double Q1 = -qs;
+    const double zeta = it * (Q1 - ctl->Q0) / Q1;
+    ctl->Q1 = Q1;
+    ctl->zeta = zeta;
+    if (zeta < q_tol && it >= min_it) { ctl->done = 1; ctl->status = 0; return; }
+    ctl->Q0 = Q1;
+    if (it >= max_it) { ctl->done = 1; ctl->status = 1; }
+  }
+}
+
+}  // namespace miba

@@ -1,0 +1,232 @@
+// miba_plan.hpp — host-side repack of the problem into the device layout.
+//
+// Replaces the host loop of BundleAdjustment::createProblem
+// (/root/reference/src/BundleAdjustment.cpp:44-86): the same observation filter (:49-60), but
+// instead of one heap-allocated cost function per observation (BAConstraint::create,
+// src/BAConstraint.cpp:82-86) the observations are sorted by point, cut into 256-slot chunks
+// that never split a point, and grouped into tiles whose distinct cameras fit an LDS
+// accumulator.  Pure C++ (no HIP): used by miba_set_problem and miba_plan_shards.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace miba {
+
+constexpr int kChunk = 256;        // observation slots per chunk = threads per block
+constexpr int kMaxCamSlots = 96;   // distinct cameras per (non-giant) tile: LDS accumulator rows
+constexpr int kMaxChunksPerTile = 4;
+constexpr int kJComp = 26;         // doubles stored per observation: F 18, E 6, r 2
+constexpr int kCamTabStride = 48;  // per-camera table row (R 9, t 3, f k1 k2, pad, dR 27, pad)
+
+struct Tile {   // 32 bytes
+  int32_t grp0, ngrp;   // groups [grp0, grp0+ngrp)
+  int32_t cam0, ncs;    // camera slots [cam0, cam0+ncs) in tile_cams / slab_row
+  int32_t giant;        // 1: single point with more than kMaxCamSlots observations
+  int32_t slot0;        // first observation slot of the tile
+  int32_t nslot;        // slots (multiple of kChunk)
+  int32_t pad;
+};
+
+struct Group {  // 16 bytes: a run of chunks that holds whole points
+  int32_t chunk0, nchunk;  // nchunk > 1 only for a giant point
+  int32_t pt0, npt;        // local (sorted) point ids [pt0, pt0+npt)
+};
+
+struct Plan {
+  int32_t n_cam = 0, n_pt_in = 0;
+  int64_t n_obs_in = 0, n_valid = 0;
+  // sorted active points (all shards)
+  std::vector<int32_t> pt_orig;          // sorted point -> caller's point id
+  std::vector<uint8_t> cam_active;       // [n_cam]
+  int32_t n_active_cam = 0;
+  // global tiling (all shards)
+  std::vector<Tile> tiles;
+  std::vector<Group> groups;
+  std::vector<int32_t> idx;              // [n_slots] pl | cs<<8, -1 = pad
+  std::vector<int32_t> ocam;             // [n_slots] global camera id (0 for pads)
+  std::vector<int64_t> slot_orig;        // [n_slots] caller's observation index, -1 = pad
+  std::vector<int32_t> pt_first;         // [n_pt] first slot of sorted point
+  std::vector<int32_t> pt_count;         // [n_pt]
+  std::vector<int32_t> tile_cams;        // per (tile, cam slot): global camera id
+  int64_t n_slots = 0;
+  // sharding: rank r owns tiles [shard_tile[r], shard_tile[r+1])
+  std::vector<int64_t> shard_tile;
+};
+
+// point_order: 0 = caller's order, 1 = sort by smallest camera index (camera locality)
+inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const int32_t* obs_cam,
+                      const int32_t* obs_pt, const double* obs_xy, const double* X, int world_size,
+                      int point_order) {
+  P = Plan();
+  P.n_cam = n_cam; P.n_pt_in = n_pt; P.n_obs_in = n_obs;
+  if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || world_size < 1) return -1;
+  if (n_cam >= (1 << 24)) return -6;
+  // --- filter (src/BundleAdjustment.cpp:49-60) and count
+  std::vector<int32_t> cnt(n_pt, 0);
+  std::vector<int32_t> mincam(n_pt, INT32_MAX);
+  std::vector<uint8_t> ok(n_obs ? n_obs : 1, 0);
+  P.cam_active.assign(n_cam, 0);
+  for (int64_t i = 0; i < n_obs; ++i) {
+    const int32_t p = obs_pt[i], c = obs_cam[i];
+    if (p == -1) continue;
+    if (p < 0 || p >= n_pt || c < 0 || c >= n_cam) return -1;
+    if (std::isnan(obs_xy[2 * i])) continue;
+    if (X && std::isnan(X[3 * (size_t)p])) continue;
+    ok[i] = 1;
+    cnt[p]++;
+    mincam[p] = std::min(mincam[p], c);
+    P.cam_active[c] = 1;
+    P.n_valid++;
+  }
+  P.n_active_cam = 0;
+  for (int c = 0; c < n_cam; ++c) P.n_active_cam += P.cam_active[c];
+  // --- order active points
+  P.pt_orig.reserve(n_pt);
+  for (int32_t p = 0; p < n_pt; ++p) if (cnt[p] > 0) P.pt_orig.push_back(p);
+  if (point_order == 1)
+    std::stable_sort(P.pt_orig.begin(), P.pt_orig.end(),
+                     [&](int32_t a, int32_t b) { return mincam[a] < mincam[b]; });
+  const int32_t n_act = (int32_t)P.pt_orig.size();
+  std::vector<int32_t> sorted_of(n_pt, -1);
+  for (int32_t s = 0; s < n_act; ++s) sorted_of[P.pt_orig[s]] = s;
+  // --- bucket observations by sorted point (stable: file order), then sort each by camera
+  std::vector<int64_t> off(n_act + 1, 0);
+  for (int32_t s = 0; s < n_act; ++s) off[s + 1] = off[s] + cnt[P.pt_orig[s]];
+  std::vector<int64_t> obs_sorted(P.n_valid ? P.n_valid : 1);
+  {
+    std::vector<int64_t> cur(off.begin(), off.end() - 1);
+    for (int64_t i = 0; i < n_obs; ++i)
+      if (ok[i]) obs_sorted[cur[sorted_of[obs_pt[i]]]++] = i;
+  }
+  for (int32_t s = 0; s < n_act; ++s)
+    std::stable_sort(obs_sorted.begin() + off[s], obs_sorted.begin() + off[s + 1],
+                     [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
+  // --- tiling
+  P.pt_first.assign(n_act, 0);
+  P.pt_count.assign(n_act, 0);
+  std::vector<int32_t> stamp(n_cam, -1), slot_of(n_cam, 0);
+  int64_t slots = 0;
+  bool tile_open = false, chunk_open = false;
+  Tile T{};
+  Group G{};
+  int chunk_fill = 0;
+  auto pad_chunk = [&]() {
+    while (slots % kChunk) { P.idx.push_back(-1); P.ocam.push_back(0); P.slot_orig.push_back(-1); ++slots; }
+  };
+  auto close_chunk = [&]() {
+    if (!chunk_open) return;
+    pad_chunk();
+    P.groups.push_back(G);
+    T.ngrp++;
+    chunk_open = false;
+    chunk_fill = 0;
+  };
+  auto close_tile = [&]() {
+    close_chunk();
+    if (!tile_open) return;
+    T.nslot = (int32_t)(slots - T.slot0);
+    P.tiles.push_back(T);
+    tile_open = false;
+  };
+  auto open_tile = [&](int giant) {
+    T = Tile{};
+    T.grp0 = (int32_t)P.groups.size();
+    T.cam0 = (int32_t)P.tile_cams.size();
+    T.giant = giant;
+    T.slot0 = (int32_t)slots;
+    tile_open = true;
+  };
+  auto open_chunk = [&](int32_t pt0) {
+    G = Group{};
+    G.chunk0 = (int32_t)(slots / kChunk);
+    G.nchunk = 1;
+    G.pt0 = pt0;
+    chunk_open = true;
+    chunk_fill = 0;
+  };
+  if ((P.n_valid + (int64_t)n_act * kChunk) >= (int64_t)INT32_MAX) return -6;  // slots are int32
+  for (int32_t s = 0; s < n_act; ++s) {
+    const int64_t a = off[s], b = off[s + 1];
+    const int32_t L = (int32_t)(b - a);
+    if (L > kMaxCamSlots) {
+      // giant point: a tile of its own, one camera slot per observation, no LDS accumulation
+      close_tile();
+      open_tile(1);
+      open_chunk(s);
+      G.npt = 1;
+      G.nchunk = (L + kChunk - 1) / kChunk;
+      P.pt_first[s] = (int32_t)slots;
+      P.pt_count[s] = L;
+      for (int64_t j = a; j < b; ++j) {
+        const int64_t i = obs_sorted[j];
+        P.idx.push_back(0);
+        P.ocam.push_back(obs_cam[i]);
+        P.slot_orig.push_back(i);
+        P.tile_cams.push_back(obs_cam[i]);
+        ++slots;
+      }
+      T.ncs = L;
+      close_tile();
+      continue;
+    }
+    // distinct new cameras this point would add to the open tile
+    const int32_t tile_id = (int32_t)P.tiles.size();
+    int add = 0;
+    if (tile_open) {
+      int32_t prev = -1;
+      for (int64_t j = a; j < b; ++j) {
+        const int32_t c = obs_cam[obs_sorted[j]];
+        if (c != prev && stamp[c] != tile_id) ++add;
+        prev = c;
+      }
+      if (T.ncs + add > kMaxCamSlots) close_tile();
+    }
+    if (tile_open && chunk_open && (chunk_fill + L > kChunk || G.npt >= 256)) {
+      close_chunk();
+      if (T.ngrp >= kMaxChunksPerTile) close_tile();
+    }
+    if (!tile_open) open_tile(0);
+    if (!chunk_open) open_chunk(s);
+    const int32_t tid = (int32_t)P.tiles.size();
+    P.pt_first[s] = (int32_t)slots;
+    P.pt_count[s] = L;
+    const int32_t pl = G.npt;
+    for (int64_t j = a; j < b; ++j) {
+      const int64_t i = obs_sorted[j];
+      const int32_t c = obs_cam[i];
+      if (stamp[c] != tid) {
+        stamp[c] = tid;
+        slot_of[c] = T.ncs++;
+        P.tile_cams.push_back(c);
+      }
+      P.idx.push_back(pl | (slot_of[c] << 8));
+      P.ocam.push_back(c);
+      P.slot_orig.push_back(i);
+      ++slots;
+    }
+    G.npt++;
+    chunk_fill += L;
+  }
+  close_tile();
+  P.n_slots = slots;
+  // --- shard tiles by cumulative slot count
+  P.shard_tile.assign(world_size + 1, 0);
+  const int64_t nt = (int64_t)P.tiles.size();
+  {
+    int64_t t = 0, acc = 0;
+    for (int r = 0; r < world_size; ++r) {
+      P.shard_tile[r] = t;
+      const int64_t target = (slots * (int64_t)(r + 1)) / world_size;
+      while (t < nt && acc + P.tiles[t].nslot / 2 < target) { acc += P.tiles[t].nslot; ++t; }
+    }
+    P.shard_tile[world_size] = nt;
+  }
+  return 0;
+}
+
+}  // namespace miba

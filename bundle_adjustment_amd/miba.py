@@ -1,0 +1,260 @@
+"""ctypes binding of libmiba.so (include/miba.h) — plumbing for tests and bench.py.
+
+The product is the C-ABI library; this module only marshals numpy arrays into it.  There is no
+CPU fallback: if libmiba.so is missing, or no GPU is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiba.so")
+
+(DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR,
+ ITERATIVE_SCHUR, CGNR) = range(7)
+CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE = range(5)
+K_EVAL_JAC, K_EVAL_COST, K_SCHUR_INIT, K_SCHUR_MATVEC, K_BACKSUB = range(5)
+K_COUNT = 8
+
+EXPORTS = [
+    "miba_default_options", "miba_create", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
+    "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
+    "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
+    "miba_plan_shards",
+]
+
+
+class MibaError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
+                ("log_level", C.c_int32), ("comm_unique_id", C.c_void_p)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("n_cam", C.c_int32), ("n_pt", C.c_int32), ("n_obs", C.c_int64),
+                ("R", C.POINTER(C.c_double)), ("T", C.POINTER(C.c_double)),
+                ("K", C.POINTER(C.c_double)), ("X", C.POINTER(C.c_double)),
+                ("obs_cam", C.POINTER(C.c_int32)), ("obs_pt", C.POINTER(C.c_int32)),
+                ("obs_xy", C.POINTER(C.c_double))]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int32), ("linear_solver_type", C.c_int32),
+                ("jacobi_scaling", C.c_int32), ("max_linear_solver_iterations", C.c_int32),
+                ("min_linear_solver_iterations", C.c_int32),
+                ("max_num_consecutive_invalid_steps", C.c_int32),
+                ("update_state_every_iteration", C.c_int32),
+                ("minimizer_progress_to_stdout", C.c_int32), ("pcg_check_every", C.c_int32),
+                ("reserved0", C.c_int32),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("eta", C.c_double), ("eta_exact", C.c_double),
+                ("max_solver_time_in_seconds", C.c_double)]
+
+
+class Iteration(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("step_is_valid", C.c_int32),
+                ("step_is_successful", C.c_int32), ("linear_solver_iterations", C.c_int32),
+                ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double),
+                ("gradient_norm", C.c_double), ("step_norm", C.c_double),
+                ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double),
+                ("eta", C.c_double), ("iteration_time_in_seconds", C.c_double),
+                ("cumulative_time_in_seconds", C.c_double), ("model_cost_change", C.c_double)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("termination_type", C.c_int32), ("num_iterations", C.c_int32),
+                ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+                ("num_linear_solver_iterations", C.c_int32), ("num_residual_blocks", C.c_int32),
+                ("num_active_cameras", C.c_int32), ("num_active_points", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("total_time_in_seconds", C.c_double), ("linear_solver_time_in_seconds", C.c_double),
+                ("jacobian_time_in_seconds", C.c_double), ("residual_time_in_seconds", C.c_double),
+                ("message", C.c_char * 128)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("launches", C.c_int64 * K_COUNT), ("total_ms", C.c_double * K_COUNT),
+                ("n_slots", C.c_int64), ("n_obs_local", C.c_int64), ("n_pt_local", C.c_int64),
+                ("n_tiles", C.c_int64), ("n_cam", C.c_int32), ("reserved", C.c_int32)]
+
+
+CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(Iteration), C.c_void_p)
+
+_lib = None
+
+
+def lib():
+    """Loads libmiba.so; raises MibaError when it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MibaError("libmiba.so is missing (%s): run __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.miba_last_error.restype = C.c_char_p
+        _lib.miba_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def default_options(**kw):
+    o = Options()
+    lib().miba_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib().miba_comm_unique_id(buf)
+    if rc != 0:
+        raise MibaError("miba_comm_unique_id rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
+    return buf.raw
+
+
+def split_cams(cams):
+    """(n,9) [w t f k1 k2] -> reference arrays R (n,3), T (n,3), K (n,6) (src/BalDataloader.cpp:143-148)."""
+    cams = np.asarray(cams, dtype=np.float64).reshape(-1, 9)
+    R = np.ascontiguousarray(cams[:, 0:3])
+    T = np.ascontiguousarray(cams[:, 3:6])
+    K = np.zeros((cams.shape[0], 6))
+    K[:, 0] = cams[:, 6]; K[:, 1] = cams[:, 6]; K[:, 4] = cams[:, 7]; K[:, 5] = cams[:, 8]
+    return R, T, K
+
+
+def join_cams(R, T, K):
+    return np.concatenate([R, T, K[:, 0:1], K[:, 4:5], K[:, 5:6]], axis=1)
+
+
+def plan_shards(n_cam, n_pt, obs_cam, obs_pt, obs_xy, world_size, X=None):
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
+    obs_xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
+    p = Problem(n_cam, n_pt, obs_cam.size, None, None, None, _dp(X) if X is not None else None,
+                _ip(obs_cam), _ip(obs_pt), _dp(obs_xy))
+    nv, nt, ns = C.c_int64(), C.c_int64(), C.c_int64()
+    tiles = (C.c_int64 * world_size)()
+    obs = (C.c_int64 * world_size)()
+    rc = lib().miba_plan_shards(C.byref(p), C.c_int32(world_size), C.byref(nv), C.byref(nt), C.byref(ns), tiles, obs)
+    if rc != 0:
+        raise MibaError("miba_plan_shards rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
+    return dict(n_valid=nv.value, n_tiles=nt.value, n_slots=ns.value, tiles_per_rank=list(tiles), obs_per_rank=list(obs))
+
+
+class Solver:
+    """One handle = one GPU (one shard).  Mirrors the miba_* entry points one to one."""
+
+    def __init__(self, device_id=-1, rank=0, world_size=1, unique_id=None, log_level=0):
+        self._h = C.c_void_p()
+        self._uid = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        cfg = Config(device_id, rank, world_size, log_level,
+                     C.cast(self._uid, C.c_void_p) if self._uid is not None else None)
+        rc = lib().miba_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise MibaError("miba_create rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
+        self.n_cam = self.n_pt = self.n_obs = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MibaError("%s rc=%d: %s" % (what, rc, (lib().miba_last_error(self._h) or b"").decode()))
+
+    def close(self):
+        if self._h:
+            lib().miba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_problem(self, cams, pts, obs_cam, obs_pt, obs_xy):
+        R, T, K = split_cams(cams)
+        X = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+        obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
+        obs_xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
+        self.n_cam, self.n_pt, self.n_obs = R.shape[0], X.shape[0], obs_cam.size
+        p = Problem(self.n_cam, self.n_pt, self.n_obs, _dp(R), _dp(T), _dp(K), _dp(X),
+                    _ip(obs_cam), _ip(obs_pt), _dp(obs_xy))
+        self._chk(lib().miba_set_problem(self._h, C.byref(p)), "miba_set_problem")
+
+    def set_state(self, cams, pts):
+        R, T, K = split_cams(cams)
+        X = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        self._chk(lib().miba_set_state(self._h, _dp(R), _dp(T), _dp(K), _dp(X)), "miba_set_state")
+
+    def get_state(self, cams_in=None, pts_in=None):
+        """Returns (cams (n,9), pts (m,3)); blocks not in the problem keep the given input values."""
+        if cams_in is not None:
+            R, T, K = split_cams(cams_in)
+        else:
+            R, T, K = np.zeros((self.n_cam, 3)), np.zeros((self.n_cam, 3)), np.zeros((self.n_cam, 6))
+        X = np.array(pts_in, dtype=np.float64).reshape(-1, 3) if pts_in is not None else np.zeros((self.n_pt, 3))
+        self._chk(lib().miba_get_state(self._h, _dp(R), _dp(T), _dp(K), _dp(X)), "miba_get_state")
+        return join_cams(R, T, K), X
+
+    def evaluate(self, jac=True, grad=True):
+        cost = C.c_double()
+        r = np.zeros((self.n_obs, 2))
+        jc = np.zeros((self.n_obs, 2, 9)) if jac else None
+        jp = np.zeros((self.n_obs, 2, 3)) if jac else None
+        gc = np.zeros((self.n_cam, 9)) if grad else None
+        gp = np.zeros((self.n_pt, 3)) if grad else None
+        self._chk(lib().miba_evaluate(self._h, C.byref(cost), _dp(r), _dp(jc), _dp(jp), _dp(gc), _dp(gp)), "miba_evaluate")
+        return dict(cost=cost.value, r=r, Jc=jc, Jp=jp, grad_cam=gc, grad_pt=gp)
+
+    def cost(self):
+        cost = C.c_double()
+        self._chk(lib().miba_evaluate(self._h, C.byref(cost), None, None, None, None, None), "miba_evaluate")
+        return cost.value
+
+    def linear_step(self, radius, options=None, probe=None):
+        o = options if options is not None else default_options()
+        yc, yp, rhs = np.zeros((self.n_cam, 9)), np.zeros((self.n_pt, 3)), np.zeros((self.n_cam, 9))
+        v = None if probe is None else np.ascontiguousarray(probe, dtype=np.float64)
+        Sv = None if probe is None else np.zeros((self.n_cam, 9))
+        ncg, mcc = C.c_int32(), C.c_double()
+        self._chk(lib().miba_linear_step(self._h, C.byref(o), C.c_double(radius), _dp(yc), _dp(yp), _dp(rhs),
+                                         _dp(v), _dp(Sv), C.byref(ncg), C.byref(mcc)), "miba_linear_step")
+        return dict(y_cam=yc, y_pt=yp, rhs=rhs, Sv=Sv, n_cg=ncg.value, model_cost_change=mcc.value)
+
+    def solve(self, options=None, callback=None):
+        o = options if options is not None else default_options()
+        s = Summary()
+        cb = CALLBACK(lambda it, user: int(callback(it.contents) or 0)) if callback else C.cast(None, CALLBACK)
+        self._chk(lib().miba_solve(self._h, C.byref(o), cb, None, C.byref(s)), "miba_solve")
+        n = C.c_int32()
+        lib().miba_get_iterations(self._h, None, 0, C.byref(n))
+        its = (Iteration * max(1, n.value))()
+        lib().miba_get_iterations(self._h, its, n.value, C.byref(n))
+        recs = [{f: getattr(its[i], f) for f, _ in Iteration._fields_} for i in range(n.value)]
+        summ = {f: getattr(s, f) for f, _ in Summary._fields_}
+        summ["message"] = summ["message"].decode(errors="replace")
+        return recs, summ
+
+    def kernel_times(self):
+        kt = KernelTimes()
+        self._chk(lib().miba_get_kernel_times(self._h, C.byref(kt)), "miba_get_kernel_times")
+        return dict(launches=list(kt.launches), total_ms=list(kt.total_ms), n_slots=kt.n_slots,
+                    n_obs_local=kt.n_obs_local, n_pt_local=kt.n_pt_local, n_tiles=kt.n_tiles, n_cam=kt.n_cam)
+
+    def reset_kernel_times(self):
+        self._chk(lib().miba_reset_kernel_times(self._h), "miba_reset_kernel_times")

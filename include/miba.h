@@ -1,0 +1,234 @@
+/*
+ * miba.h — C ABI of libmiba: the MI355X-native (gfx950, HIP) Levenberg-Marquardt /
+ * implicit-Schur-PCG bundle-adjustment solver that replaces the Ceres-backed inner loop of
+ * Dawars/bundle_adjustment behind its BundleAdjustment / BAConstraint C++ API.
+ *
+ * Plain pointers and sizes only; no C++/torch/HIP types.  Every entry point returns an int
+ * status (MIBA_OK = 0, < 0 error); miba_last_error() gives the text.  The library copies
+ * caller data in at miba_set_problem()/miba_set_state() and out at miba_get_state(); it
+ * never keeps caller pointers.  A handle is not thread-safe.  One handle drives ONE GPU;
+ * multi-GPU runs use one process (one handle) per GPU, joined by an RCCL communicator.
+ *
+ * There is NO CPU fallback: every compute entry point fails with MIBA_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ *
+ * Reference interfaces replaced (paths under /root/reference):
+ *   miba_set_problem  <- BundleAdjustment::createProblem            src/BundleAdjustment.cpp:39-96
+ *                        (filter :49-60, one residual block per observation :67-74,
+ *                         BAConstraint::create src/BAConstraint.cpp:82-86)
+ *   miba_set_state    <- Dataloader::initialize into R,T,intrinsics,X   src/BundleAdjustment.cpp:22-27
+ *   miba_solve        <- ceres::Solve(options,&problem,&summary)    src/BundleAdjustment.cpp:98-113
+ *   miba_get_state    <- update_state_every_iteration + getRotation/getTranslation/
+ *                        getIntrinsics/getPoint                     src/BundleAdjustment.cpp:104,115-129
+ *   miba_evaluate     <- BAConstraint::operator()<double / Jet>     src/BAConstraint.cpp:15-80
+ *                        (as called by ceres::Problem::Evaluate)
+ *   miba_options      <- ceres::Solver::Options fields used at      app/main.cpp:21-28,
+ *                                                                   src/BundleAdjustment.cpp:104-105
+ *   miba_iteration    <- ceres::IterationSummary (callback argument) src/MeshWriterCallback.h:17-23
+ *   miba_summary      <- ceres::Solver::Summary                     src/BundleAdjustment.cpp:107-110
+ */
+#ifndef MIBA_H
+#define MIBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct miba_handle_s* miba_handle;
+
+enum {
+  MIBA_OK = 0,
+  MIBA_ERR_INVALID = -1,    /* bad argument / call order */
+  MIBA_ERR_NO_DEVICE = -2,  /* no usable HIP device (there is no CPU fallback) */
+  MIBA_ERR_HIP = -3,        /* a HIP runtime call failed */
+  MIBA_ERR_RCCL = -4,       /* an RCCL call failed */
+  MIBA_ERR_NOMEM = -5,
+  MIBA_ERR_LIMIT = -6       /* problem exceeds a documented limit (e.g. n_cam >= 2^24) */
+};
+
+/* mirrors ceres::LinearSolverType as far as app/main.cpp:19 / BundleAdjustment.cpp:20 use it */
+enum {
+  MIBA_DENSE_NORMAL_CHOLESKY = 0,
+  MIBA_DENSE_QR = 1,
+  MIBA_SPARSE_NORMAL_CHOLESKY = 2,
+  MIBA_DENSE_SCHUR = 3,
+  MIBA_SPARSE_SCHUR = 4,
+  MIBA_ITERATIVE_SCHUR = 5, /* device implicit-Schur PCG: the north-star path */
+  MIBA_CGNR = 6
+};
+
+/* mirrors ceres::TerminationType */
+enum { MIBA_CONVERGENCE = 0, MIBA_NO_CONVERGENCE = 1, MIBA_FAILURE = 2, MIBA_USER_SUCCESS = 3, MIBA_USER_FAILURE = 4 };
+
+/* mirrors ceres::CallbackReturnType (src/MeshWriterCallback.h:22) */
+enum { MIBA_SOLVER_CONTINUE = 0, MIBA_SOLVER_ABORT = 1, MIBA_SOLVER_TERMINATE_SUCCESSFULLY = 2 };
+
+typedef struct {
+  int32_t device_id;   /* HIP device ordinal, -1 = current device */
+  int32_t rank;        /* shard owned by this process, 0 <= rank < world_size */
+  int32_t world_size;  /* number of point shards (= processes = GPUs) */
+  int32_t log_level;   /* 0 silent, 1 summary, 2 per-iteration */
+  /* 128-byte RCCL unique id from miba_comm_unique_id() on rank 0, broadcast by the caller
+   * (e.g. torch.distributed); NULL when world_size == 1. */
+  const void* comm_unique_id;
+} miba_config;
+
+typedef struct {
+  int32_t n_cam;
+  int32_t n_pt;
+  int64_t n_obs;
+  /* parameter arrays in the reference layout (src/BundleAdjustment.cpp:22-25):
+   * R[3*n_cam] angle-axis, T[3*n_cam], K[6*n_cam] = fx,fy,ox,oy,k1,k2 (BAL: fx=fy=f, ox=oy=0;
+   * src/BalDataloader.cpp:143-148), X[3*n_pt]. */
+  const double* R;
+  const double* T;
+  const double* K;
+  const double* X;
+  /* observations in the caller's (file) order; obs_pt == -1, NaN observation or NaN point
+   * are skipped exactly as src/BundleAdjustment.cpp:49-60 does. obs_xy = x0,y0,x1,y1,...
+   * (float-rounded values widened to double). */
+  const int32_t* obs_cam;
+  const int32_t* obs_pt;
+  const double* obs_xy;
+} miba_problem;
+
+typedef struct {
+  int32_t max_num_iterations;               /* app/main.cpp:27 -> 80; Ceres default 50 */
+  int32_t linear_solver_type;               /* MIBA_* above; all but ITERATIVE_SCHUR are run
+                                               as tight-tolerance PCG (eta_exact) and reported so */
+  int32_t jacobi_scaling;                   /* 1 */
+  int32_t max_linear_solver_iterations;     /* 500 */
+  int32_t min_linear_solver_iterations;     /* 0 */
+  int32_t max_num_consecutive_invalid_steps;/* 5 */
+  int32_t update_state_every_iteration;     /* src/BundleAdjustment.cpp:104 */
+  int32_t minimizer_progress_to_stdout;     /* app/main.cpp:26 */
+  int32_t pcg_check_every;                  /* host polls the device PCG status every N its (>=1) */
+  int32_t reserved0;
+  double initial_trust_region_radius;       /* 1e4 */
+  double max_trust_region_radius;           /* 1e16 */
+  double min_trust_region_radius;           /* 1e-32 */
+  double min_relative_decrease;             /* 1e-3 */
+  double min_lm_diagonal;                   /* 1e-6 */
+  double max_lm_diagonal;                   /* 1e32 */
+  double function_tolerance;                /* 1e-6 */
+  double gradient_tolerance;                /* 1e-10 */
+  double parameter_tolerance;               /* 1e-8 */
+  double eta;                               /* 1e-1 */
+  double eta_exact;                         /* q-tolerance used for the non-iterative solver types (1e-12) */
+  double max_solver_time_in_seconds;        /* 1e9 */
+} miba_options;
+
+typedef struct {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t linear_solver_iterations;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double gradient_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  double eta;
+  double iteration_time_in_seconds;
+  double cumulative_time_in_seconds;
+  double model_cost_change;
+} miba_iteration;
+
+typedef struct {
+  int32_t termination_type;
+  int32_t num_iterations;           /* LM iterations run (successful + unsuccessful), iteration 0 excluded */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_linear_solver_iterations; /* total PCG iterations */
+  int32_t num_residual_blocks;      /* observations that survived the filter (all shards) */
+  int32_t num_active_cameras;
+  int32_t num_active_points;
+  double initial_cost;
+  double final_cost;
+  double total_time_in_seconds;     /* inside miba_solve, excluding callbacks */
+  double linear_solver_time_in_seconds;
+  double jacobian_time_in_seconds;
+  double residual_time_in_seconds;
+  char message[128];
+} miba_summary;
+
+/* per-iteration callback: return one of MIBA_SOLVER_*.  When
+ * options.update_state_every_iteration != 0 the current state can be read with
+ * miba_get_state() from inside the callback. */
+typedef int (*miba_iteration_callback)(const miba_iteration* it, void* user);
+
+/* Kernel ids for miba_get_kernel_times */
+enum {
+  MIBA_K_EVAL_JAC = 0,   /* K1  residual + Jacobian              */
+  MIBA_K_EVAL_COST = 1,  /* K1' residual-only cost               */
+  MIBA_K_SCHUR_INIT = 2, /* K2  per-point Schur init + camera block sums */
+  MIBA_K_SCHUR_MATVEC = 3, /* K3 implicit Schur mat-vec          */
+  MIBA_K_BACKSUB = 4,    /* K4  back-substitution + model cost change */
+  MIBA_K_COUNT = 8
+};
+
+typedef struct {
+  int64_t launches[MIBA_K_COUNT];
+  double total_ms[MIBA_K_COUNT];   /* HIP-event time on the launch stream */
+  int64_t n_slots;                 /* padded observation slots on this shard */
+  int64_t n_obs_local;             /* real observations on this shard */
+  int64_t n_pt_local;
+  int64_t n_tiles;
+  int32_t n_cam;
+  int32_t reserved;
+} miba_kernel_times;
+
+void miba_default_options(miba_options* o);
+
+int miba_create(const miba_config* cfg, miba_handle* out);
+int miba_destroy(miba_handle h);
+/* text of the last error on this handle (h may be NULL: last error of a failed miba_create) */
+const char* miba_last_error(miba_handle h);
+/* 128 bytes; call on rank 0 only, then broadcast */
+int miba_comm_unique_id(void* out128);
+
+int miba_set_problem(miba_handle h, const miba_problem* p);
+int miba_set_state(miba_handle h, const double* R, const double* T, const double* K, const double* X);
+int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X);
+
+/* Cost, and optionally residuals (2*n_obs), camera Jacobian blocks (18*n_obs, 2x9 row-major,
+ * columns w0 w1 w2 t0 t1 t2 f k1 k2), point Jacobian blocks (6*n_obs, 2x3 row-major), all in
+ * the CALLER'S observation order (skipped observations are zero-filled), and the gradient
+ * J'r for cameras (9*n_cam) and points (3*n_pt).  Unscaled Jacobian, r = predicted - observed.
+ * Any output pointer may be NULL.  With world_size > 1 each rank fills only its shard's
+ * observations/points; cost and camera gradient are all-reduced. */
+int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_cam, double* jac_pt,
+                  double* grad_cam, double* grad_pt);
+
+int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback cb, void* user,
+               miba_summary* summary);
+/* iteration records of the last miba_solve (iteration 0 first); *n = records available */
+int miba_get_iterations(miba_handle h, miba_iteration* out, int32_t max, int32_t* n);
+
+/* One damped linear solve at the current state (kernel-level parity hook): Jacobi scale at
+ * the current state (if options.jacobi_scaling), D = sqrt(clamp(diag J'J)/radius), implicit
+ * Schur PCG, back-substitution.  Outputs (any may be NULL): y_cam (9*n_cam) and y_pt (3*n_pt)
+ * = solution of (J'J + D'D) y = J'r in scaled coordinates (before the LM negation), the
+ * reduced right-hand side rhs (9*n_cam), S*probe for an optional probe vector (9*n_cam),
+ * PCG iteration count and model cost change. */
+int miba_linear_step(miba_handle h, const miba_options* opt, double radius, double* y_cam,
+                     double* y_pt, double* rhs, const double* probe, double* s_probe,
+                     int32_t* n_cg, double* model_cost_change);
+
+int miba_get_kernel_times(miba_handle h, miba_kernel_times* out);
+int miba_reset_kernel_times(miba_handle h);
+
+/* Host-only planning helper (needs no GPU): how set_problem would tile and shard a problem.
+ * tiles_per_rank / obs_per_rank have world_size entries. */
+int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid_obs,
+                     int64_t* n_tiles, int64_t* n_slots, int64_t* tiles_per_rank,
+                     int64_t* obs_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

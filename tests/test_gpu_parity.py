@@ -1,0 +1,215 @@
+"""GPU parity tests: the HIP path (through the C ABI, libmiba.so) against the CPU oracle and the
+committed golden fixtures.  Tolerances follow BASELINE.json north_star: residuals and Jacobians
+within 1e-10 relative (to the block max-norm), final cost after a fixed iteration count within
+1e-6 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import miba, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REL_J = 1e-10       # north_star bound for residuals / Jacobians
+REL_COST = 1e-6     # north_star bound for the final cost
+
+
+def rel(a, b):
+    m = np.abs(b).max()
+    return np.abs(a - b).max() / (m if m > 0 else 1.0)
+
+
+@pytest.fixture(scope="module")
+def medium():
+    pr = synth.make_problem(40, 3000, 14000, seed=11, shuffle_obs=True)
+    cams0, pts0 = synth.perturb(pr, 0.01, 0.1, seed=12)
+    return pr, cams0, pts0
+
+
+def make_solver(pr, cams, pts):
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams, pts, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    return s
+
+
+def test_golden_vectors_through_hip():
+    """mpmath 50-digit residual/Jacobian fixtures (tools/gen_golden.py), every case its own
+    camera/point/observation, evaluated by K0/K1 on the GPU."""
+    g = json.load(open(os.path.join(GOLD, "proj_golden.json")))
+    cs = g["cases"]
+    n = len(cs)
+    cams = np.array([[float.fromhex(h) for h in c["cam_hex"]] for c in cs])
+    pts = np.array([[float.fromhex(h) for h in c["X_hex"]] for c in cs])
+    obs = np.array([[float.fromhex(h) for h in c["obs_hex"]] for c in cs])
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams, pts, np.arange(n), np.arange(n), obs)
+    ev = s.evaluate(jac=True, grad=False)
+    s.close()
+    worst = 0.0
+    for i, c in enumerate(cs):
+        R = np.array([float(v) for v in c["r"]])
+        JC = np.array([[float(v) for v in row] for row in c["Jc"]])
+        JP = np.array([[float(v) for v in row] for row in c["Jp"]])
+        pred = max(1.0, np.abs(R + obs[i]).max())
+        errs = [np.abs(ev["r"][i] - R).max() / pred]
+        for a, b in [(ev["Jc"][i][:, 0:3], JC[:, 0:3]), (ev["Jc"][i][:, 3:6], JC[:, 3:6]),
+                     (ev["Jc"][i][:, 6:7], JC[:, 6:7]), (ev["Jc"][i][:, 7:8], JC[:, 7:8]),
+                     (ev["Jc"][i][:, 8:9], JC[:, 8:9]), (ev["Jp"][i], JP)]:
+            errs.append(rel(a, b))
+        worst = max(worst, max(errs))
+        assert max(errs) <= REL_J, (i, c["small_angle"], errs)
+    print("golden worst rel err", worst)
+
+
+def test_evaluate_matches_oracle(oracle, medium):
+    pr, cams0, pts0 = medium
+    s = make_solver(pr, cams0, pts0)
+    ev = s.evaluate()
+    s.close()
+    ref = oracle.evaluate(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    assert abs(ev["cost"] - ref["cost"]) <= 1e-12 * ref["cost"]
+    # per observation, relative to that observation's block max-norm
+    for name in ("Jc", "Jp"):
+        a, b = ev[name], ref[name]
+        m = np.abs(b).reshape(b.shape[0], -1).max(1)
+        e = np.abs(a - b).reshape(b.shape[0], -1).max(1) / np.maximum(m, 1e-300)
+        assert e.max() <= REL_J, (name, e.max())
+    pred = np.abs(ref["r"] + pr["obs_xy"]).max(1)
+    assert (np.abs(ev["r"] - ref["r"]).max(1) / np.maximum(pred, 1.0)).max() <= REL_J
+    assert rel(ev["grad_cam"], ref["grad_cam"]) <= 1e-10
+    assert rel(ev["grad_pt"], ref["grad_pt"]) <= 1e-10
+
+
+def test_filter_skips_invalid_observations(oracle, medium):
+    """obs_pt == -1, NaN observation, NaN point (src/BundleAdjustment.cpp:49-60)."""
+    pr, cams0, pts0 = medium
+    oc, op, oxy = pr["obs_cam"].copy(), pr["obs_pt"].copy(), pr["obs_xy"].copy()
+    pts = pts0.copy()
+    op[5] = -1
+    oxy[17, 0] = np.nan
+    bad_pt = int(op[100])
+    pts[bad_pt, 0] = np.nan
+    keep = (op != -1) & ~np.isnan(oxy[:, 0]) & (op != bad_pt)
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams0, pts, oc, op, oxy)
+    ev = s.evaluate(jac=True, grad=False)
+    s.close()
+    pts_ref = pts.copy()
+    pts_ref[bad_pt] = 0.0
+    ref = oracle.evaluate(cams0, pts_ref, oc[keep], op[keep], oxy[keep], grad=False)
+    assert abs(ev["cost"] - ref["cost"]) <= 1e-12 * ref["cost"]
+    assert np.all(ev["r"][~keep] == 0.0) and np.all(ev["Jc"][~keep] == 0.0)
+    assert rel(ev["Jc"][keep], ref["Jc"]) <= REL_J
+
+
+def test_linear_step_matches_oracle(oracle, medium):
+    """K2 (Schur init), K3 (S*v), PCG and K4 (back-substitution, model cost change) at one state."""
+    pr, cams0, pts0 = medium
+    rng = np.random.default_rng(5)
+    probe = rng.normal(size=(pr["n_cam"], 9))
+    s = make_solver(pr, cams0, pts0)
+    opt = miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, eta_exact=1e-14, max_linear_solver_iterations=2000)
+    out = s.linear_step(1e4, opt, probe=probe)
+    s.close()
+    sc, sp = oracle.jacobi_scale(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    ref = oracle.linear_step(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], 1e4, sc, sp,
+                             oracle.default_options(linear_solver=oracle.DENSE_SCHUR), probe=probe)
+    assert ref["rc"] == 0
+    assert rel(out["rhs"], ref["rhs"]) <= 1e-10
+    assert rel(out["Sv"], ref["Sv"]) <= 1e-10
+    assert rel(out["y_cam"], ref["y_cam"]) <= 1e-7
+    assert rel(out["y_pt"], ref["y_pt"]) <= 1e-7
+    assert abs(out["model_cost_change"] - ref["model_cost_change"]) <= 1e-9 * abs(ref["model_cost_change"])
+
+
+def test_iterative_schur_same_iteration_count(oracle, medium):
+    """ITERATIVE_SCHUR (eta = 0.1): same PCG recurrence as the oracle => same iteration count and step."""
+    pr, cams0, pts0 = medium
+    s = make_solver(pr, cams0, pts0)
+    out = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR))
+    s.close()
+    sc, sp = oracle.jacobi_scale(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    ref = oracle.linear_step(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], 1e4, sc, sp,
+                             oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR))
+    assert out["n_cg"] == ref["n_cg"], (out["n_cg"], ref["n_cg"])
+    assert rel(out["y_cam"], ref["y_cam"]) <= 1e-8
+    assert rel(out["y_pt"], ref["y_pt"]) <= 1e-8
+
+
+@pytest.mark.parametrize("solver", ["exact", "iterative"])
+def test_lm_trajectory_matches_oracle(oracle, medium, solver):
+    pr, cams0, pts0 = medium
+    n_it = 12
+    if solver == "exact":
+        mo = miba.default_options(max_num_iterations=n_it, linear_solver_type=miba.SPARSE_SCHUR,
+                                  function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+        oo = oracle.default_options(max_num_iterations=n_it, linear_solver=oracle.DENSE_SCHUR,
+                                    function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+        tol = 1e-8
+    else:
+        mo = miba.default_options(max_num_iterations=n_it, linear_solver_type=miba.ITERATIVE_SCHUR,
+                                  function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+        oo = oracle.default_options(max_num_iterations=n_it, linear_solver=oracle.ITERATIVE_SCHUR,
+                                    function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+        tol = REL_COST
+    s = make_solver(pr, cams0, pts0)
+    its, summ = s.solve(mo)
+    cams, pts = s.get_state(cams0, pts0)
+    s.close()
+    ocams, opts, oits, osumm = oracle.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], oo)
+    assert len(its) == len(oits)
+    for a, b in zip(its, oits):
+        assert a["iteration"] == b["iteration"]
+        assert abs(a["cost"] - b["cost"]) <= tol * abs(b["cost"]), (a, b)
+        assert a["step_is_successful"] == b["step_is_successful"]
+        if solver == "exact":
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"]
+            assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-6 * b["gradient_max_norm"] + 1e-9
+    assert abs(summ["final_cost"] - osumm["final_cost"]) <= REL_COST * osumm["final_cost"]
+    # the state handed back is the state whose cost is reported
+    assert abs(oracle.evaluate(cams, pts, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], jac=False, grad=False)["cost"]
+               - summ["final_cost"]) <= 1e-10 * summ["final_cost"]
+
+
+def test_giant_and_tiny_tracks(oracle):
+    """A point seen by more cameras than a tile's LDS camera slots (and by more than one chunk),
+    next to ordinary points: exercises the giant-tile paths of K2/K3/K4."""
+    rng = np.random.default_rng(3)
+    pr = synth.make_problem(900, 300, 1500, seed=21)
+    # add one point observed by 700 cameras and one by 120 cameras
+    cams = pr["cams"]
+    extra_pts = np.array([[0.3, -0.2, 0.1], [1.0, 0.5, -0.3]])
+    pts = np.concatenate([pr["pts"], extra_pts])
+    oc, op, oxy = [pr["obs_cam"]], [pr["obs_pt"]], [pr["obs_xy"]]
+    for j, ncams in enumerate((700, 120)):
+        cs = rng.choice(900, size=ncams, replace=False).astype(np.int32)
+        ps = np.full(ncams, 300 + j, dtype=np.int32)
+        xy, z = synth.project(cams, pts, cs, ps)
+        ok = z < 0
+        oc.append(cs[ok]); op.append(ps[ok]); oxy.append(xy[ok] + rng.normal(0, 0.5, xy[ok].shape))
+    oc, op, oxy = np.concatenate(oc), np.concatenate(op), np.concatenate(oxy)
+    perm = rng.permutation(oc.size)
+    oc, op, oxy = oc[perm], op[perm], oxy[perm]
+    cams0 = cams.copy(); cams0[:, 0:6] += rng.normal(0, 0.003, (900, 6))
+    pts0 = pts + rng.normal(0, 0.05, pts.shape)
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams0, pts0, oc, op, oxy)
+    ev = s.evaluate()
+    ref = oracle.evaluate(cams0, pts0, oc, op, oxy)
+    assert rel(ev["Jc"], ref["Jc"]) <= REL_J and rel(ev["grad_cam"], ref["grad_cam"]) <= 1e-10
+    assert rel(ev["grad_pt"], ref["grad_pt"]) <= 1e-10
+    probe = rng.normal(size=(900, 9))
+    out = s.linear_step(1e3, miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, eta_exact=1e-14,
+                                                  max_linear_solver_iterations=3000), probe=probe)
+    sc, sp = oracle.jacobi_scale(cams0, pts0, oc, op, oxy)
+    refl = oracle.linear_step(cams0, pts0, oc, op, oxy, 1e3, sc, sp,
+                              oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, eta=1e-14,
+                                                     max_linear_solver_iterations=3000), probe=probe)
+    s.close()
+    assert rel(out["rhs"], refl["rhs"]) <= 1e-10
+    assert rel(out["Sv"], refl["Sv"]) <= 1e-10
+    assert rel(out["y_pt"], refl["y_pt"]) <= 1e-6
+    assert abs(out["model_cost_change"] - refl["model_cost_change"]) <= 1e-8 * abs(refl["model_cost_change"])
