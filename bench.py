@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — LM iterations/sec of the HIP bundle-adjustment hot path on BAL Final-13682.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU.
+A "step" is one Levenberg-Marquardt iteration (successful or not) of miba_solve on the synthetic
+BAL-format stand-in for Final-13682 (13,682 cameras / 4,456,117 points / 28,987,644 observations,
+seed 13682; no BAL file exists here).  W warm-up iterations, then exactly K timed iterations
+between barrier + device-sync brackets; the problem is resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="final-13682")
+    ap.add_argument("--sigma-cam", type=float, default=1e-3)
+    ap.add_argument("--sigma-x", type=float, default=0.05)
+    ap.add_argument("--eta", type=float, default=0.1)
+    ap.add_argument("--check-every", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    from bundle_adjustment_amd import miba, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    uid = None
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")
+        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(miba.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        uid = bytes(t.cpu().numpy().tobytes())
+
+    n_cam, n_pt, n_obs, seed = synth.CONFIGS[args.config]
+    t0 = time.time()
+    pr = synth.make_problem(n_cam, n_pt, n_obs, seed=seed)
+    cams0, pts0 = synth.perturb(pr, args.sigma_cam, args.sigma_x, seed=seed + 1)
+    t_gen = time.time() - t0
+
+    solver = miba.Solver(device_id=local_rank, rank=rank, world_size=world, unique_id=uid)
+    t0 = time.time()
+    solver.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    t_setup = time.time() - t0
+
+    total = args.warmup + args.steps
+    opt = miba.default_options(max_num_iterations=total, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
+                               function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
+                               pcg_check_every=args.check_every)
+    marks = {}
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def cb(it):
+        if it.iteration == args.warmup:
+            sync()
+            solver.reset_kernel_times()
+            marks["t0"] = time.perf_counter()
+        if it.iteration == total:
+            sync()
+            marks["t1"] = time.perf_counter()
+        return 0
+
+    its, summ = solver.solve(opt, callback=cb)
+    if "t0" not in marks or "t1" not in marks:
+        raise SystemExit("solver stopped before %d iterations: %s" % (total, summ["message"]))
+    dt = marks["t1"] - marks["t0"]
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kt = solver.kernel_times()
+
+    timed = [r for r in its if args.warmup < r["iteration"] <= total]
+    n_cg = sum(r["linear_solver_iterations"] for r in timed)
+    # dominant kernel: K3 implicit-Schur mat-vec. Algorithmic bytes per launch:
+    # 196*o + 48*m + 144*n with this rank's observations o and points m, n cameras.
+    o_loc, m_loc = kt["n_obs_local"], kt["n_pt_local"]
+    k3_bytes = 196.0 * o_loc + 48.0 * m_loc + 144.0 * n_cam
+    k3_n = kt["launches"][miba.K_SCHUR_MATVEC]
+    k3_ms = kt["total_ms"][miba.K_SCHUR_MATVEC] / max(1, k3_n)
+    achieved = k3_bytes / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
+    kern = {}
+    names = {miba.K_EVAL_JAC: ("K1_eval_jac", 228.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
+             miba.K_EVAL_COST: ("K1p_eval_cost", 20.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
+             miba.K_SCHUR_INIT: ("K2_schur_init", 212.0 * o_loc + 72.0 * m_loc + 720.0 * n_cam),
+             miba.K_SCHUR_MATVEC: ("K3_schur_matvec", k3_bytes),
+             miba.K_BACKSUB: ("K4_backsub", 212.0 * o_loc + 96.0 * m_loc + 72.0 * n_cam)}
+    for kid, (nm, by) in names.items():
+        n = kt["launches"][kid]
+        ms = kt["total_ms"][kid] / max(1, n)
+        kern[nm] = {"launches": n, "avg_ms": round(ms, 4), "algorithmic_GBs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+
+    out = {
+        "metric": "LM iters/sec on BAL Final-13682",
+        "value": args.steps / dt,
+        "unit": "LM iterations/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "synthetic BAL-format stand-in for %s: %d cameras / %d points / %d observations, seed %d, "
+                               "initial state = ground truth + N(0,%g) on camera rot/trans + N(0,%g) on points; "
+                               "LM + ITERATIVE_SCHUR (implicit Schur, JACOBI preconditioner, eta=%g)"
+                               % (args.config, n_cam, n_pt, n_obs, seed, args.sigma_cam, args.sigma_x, args.eta),
+                   "pcg_iterations_in_timed_steps": n_cg,
+                   "successful_steps_in_timed_steps": sum(r["step_is_successful"] for r in timed),
+                   "cost_first": its[0]["cost"], "cost_last": summ["final_cost"],
+                   "parallelism": "points sharded over %d GPU(s), cameras replicated, RCCL all-reduce" % args.gpus},
+        "roofline": {"bound": "hbm", "kernel": "k_schur_matvec (K3)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": k3_ms, "launches": k3_n, "algorithmic_bytes_per_launch": k3_bytes},
+        "kernels": kern,
+        "setup": {"generate_s": round(t_gen, 2), "set_problem_s": round(t_setup, 2), "tiles": kt["n_tiles"],
+                  "slots": kt["n_slots"]},
+    }
+
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle (a port, oracle/ba_oracle.c) on the host cores, same problem and
+        # initial state, bounded to cpu_iters LM iterations after iteration 0.
+        from oracle import oracle as O
+        cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+        oo = O.default_options(max_num_iterations=args.cpu_iters, linear_solver=O.ITERATIVE_SCHUR, eta=args.eta,
+                               function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0, num_threads=cores)
+        _, _, oits, osumm = O.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], oo)
+        t_cpu = sum(r["iteration_time_s"] for r in oits[1:])
+        n_cpu = len(oits) - 1
+        same = [abs(a["cost"] - b["cost"]) / b["cost"] for a, b in zip(its[1:1 + n_cpu], oits[1:])]
+        out["cpu_baseline"] = {"value": n_cpu / t_cpu if t_cpu > 0 else None, "unit": "LM iterations/s", "cores": cores,
+                               "kind": "port",
+                               "sample": "first %d LM iteration(s) of the same problem and initial state (%d PCG iterations), "
+                                         "oracle/ba_oracle.c with OpenMP; cost after them agrees with the HIP path to %.1e relative"
+                                         % (n_cpu, sum(r["linear_solver_iterations"] for r in oits[1:]), max(same) if same else 0.0)}
+    if rank == 0:
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,9 +120,17 @@ def test_linear_step_matches_oracle(oracle, medium):
     assert ref["rc"] == 0
     assert rel(out["rhs"], ref["rhs"]) <= 1e-10
     assert rel(out["Sv"], ref["Sv"]) <= 1e-10
-    assert rel(out["y_cam"], ref["y_cam"]) <= 1e-7
-    assert rel(out["y_pt"], ref["y_pt"]) <= 1e-7
+    # the Q-tolerance stop leaves the weakly determined (gauge) directions slightly unconverged:
+    # loose against the exact dense-Schur solve, tight against the oracle's PCG run the same way
+    assert rel(out["y_cam"], ref["y_cam"]) <= 1e-4
+    assert rel(out["y_pt"], ref["y_pt"]) <= 1e-4
     assert abs(out["model_cost_change"] - ref["model_cost_change"]) <= 1e-9 * abs(ref["model_cost_change"])
+    ref2 = oracle.linear_step(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], 1e4, sc, sp,
+                              oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, eta=1e-14,
+                                                     max_linear_solver_iterations=2000))
+    assert abs(out["n_cg"] - ref2["n_cg"]) <= 0.1 * ref2["n_cg"], (out["n_cg"], ref2["n_cg"])
+    assert rel(out["y_cam"], ref2["y_cam"]) <= 1e-6
+    assert rel(out["y_pt"], ref2["y_pt"]) <= 1e-6
 
 
 def test_iterative_schur_same_iteration_count(oracle, medium):
@@ -139,35 +147,42 @@ def test_iterative_schur_same_iteration_count(oracle, medium):
     assert rel(out["y_pt"], ref["y_pt"]) <= 1e-8
 
 
-@pytest.mark.parametrize("solver", ["exact", "iterative"])
+@pytest.mark.parametrize("solver", ["exact", "iterative", "iterative_tight"])
 def test_lm_trajectory_matches_oracle(oracle, medium, solver):
+    """Per-iteration table against the oracle.  Iterations are compared while the oracle still makes
+    progress (|cost_change| > 1e-9 cost); beyond that rho = cost_change / model_cost_change is
+    rounding noise on both sides and accept/reject decisions are not comparable."""
     pr, cams0, pts0 = medium
     n_it = 12
+    kw = dict(max_num_iterations=n_it, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
     if solver == "exact":
-        mo = miba.default_options(max_num_iterations=n_it, linear_solver_type=miba.SPARSE_SCHUR,
-                                  function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
-        oo = oracle.default_options(max_num_iterations=n_it, linear_solver=oracle.DENSE_SCHUR,
-                                    function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
-        tol = 1e-8
-    else:
-        mo = miba.default_options(max_num_iterations=n_it, linear_solver_type=miba.ITERATIVE_SCHUR,
-                                  function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
-        oo = oracle.default_options(max_num_iterations=n_it, linear_solver=oracle.ITERATIVE_SCHUR,
-                                    function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+        # device: tight-tolerance PCG; oracle: explicit dense Schur + Cholesky
+        mo = miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, **kw)
+        oo = oracle.default_options(linear_solver=oracle.DENSE_SCHUR, **kw)
         tol = REL_COST
+    else:
+        eta = 0.1 if solver == "iterative" else 1e-12
+        mo = miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, eta=eta, **kw)
+        oo = oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, eta=eta, **kw)
+        tol = 1e-9
     s = make_solver(pr, cams0, pts0)
     its, summ = s.solve(mo)
     cams, pts = s.get_state(cams0, pts0)
     s.close()
     ocams, opts, oits, osumm = oracle.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], oo)
-    assert len(its) == len(oits)
-    for a, b in zip(its, oits):
+    n_cmp = 1
+    while n_cmp < len(oits) and abs(oits[n_cmp]["cost_change"]) > 1e-9 * oits[n_cmp]["cost"]:
+        n_cmp += 1
+    assert n_cmp >= 4 and len(its) >= n_cmp
+    for a, b in zip(its[:n_cmp], oits[:n_cmp]):
         assert a["iteration"] == b["iteration"]
         assert abs(a["cost"] - b["cost"]) <= tol * abs(b["cost"]), (a, b)
         assert a["step_is_successful"] == b["step_is_successful"]
-        if solver == "exact":
-            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"]
-            assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-6 * b["gradient_max_norm"] + 1e-9
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-4 * b["trust_region_radius"]
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-4 * b["gradient_max_norm"] + 1e-9
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-3 * b["step_norm"] + 1e-12
+        if solver == "iterative":
+            assert a["linear_solver_iterations"] == b["linear_solver_iterations"]
     assert abs(summ["final_cost"] - osumm["final_cost"]) <= REL_COST * osumm["final_cost"]
     # the state handed back is the state whose cost is reported
     assert abs(oracle.evaluate(cams, pts, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], jac=False, grad=False)["cost"]
