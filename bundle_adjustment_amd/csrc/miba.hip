@@ -556,6 +556,20 @@ int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid
   return MIBA_OK;
 }
 
+int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* owner) {
+  if (!p || !owner) return fail(nullptr, MIBA_ERR_INVALID, "null argument");
+  Plan P;
+  const char* po = getenv("MIBA_POINT_ORDER");
+  int rc = build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, world_size, po ? atoi(po) : 1);
+  if (rc) return fail(nullptr, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d)", rc);
+  for (int32_t i = 0; i < p->n_pt; ++i) owner[i] = -1;
+  for (int r = 0; r < world_size; ++r)
+    for (int64_t t = P.shard_tile[r]; t < P.shard_tile[r + 1]; ++t)
+      for (int32_t g = P.tiles[t].grp0; g < P.tiles[t].grp0 + P.tiles[t].ngrp; ++g)
+        for (int32_t q = P.groups[g].pt0; q < P.groups[g].pt0 + P.groups[g].npt; ++q) owner[P.pt_orig[q]] = r;
+  return MIBA_OK;
+}
+
 int miba_set_problem(miba_handle h, const miba_problem* p) {
   if (!h || !p) return fail(h, MIBA_ERR_INVALID, "null argument");
   if (!p->R || !p->T || !p->K || !p->X || (p->n_obs > 0 && (!p->obs_cam || !p->obs_pt || !p->obs_xy)))

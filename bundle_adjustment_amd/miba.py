@@ -21,7 +21,7 @@ EXPORTS = [
     "miba_default_options", "miba_create", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
-    "miba_plan_shards",
+    "miba_plan_shards", "miba_plan_point_owner",
 ]
 
 
@@ -155,6 +155,18 @@ def plan_shards(n_cam, n_pt, obs_cam, obs_pt, obs_xy, world_size, X=None):
     if rc != 0:
         raise MibaError("miba_plan_shards rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
     return dict(n_valid=nv.value, n_tiles=nt.value, n_slots=ns.value, tiles_per_rank=list(tiles), obs_per_rank=list(obs))
+
+
+def plan_point_owner(n_cam, n_pt, obs_cam, obs_pt, obs_xy, world_size):
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
+    obs_xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
+    p = Problem(n_cam, n_pt, obs_cam.size, None, None, None, None, _ip(obs_cam), _ip(obs_pt), _dp(obs_xy))
+    owner = np.zeros(n_pt, dtype=np.int32)
+    rc = lib().miba_plan_point_owner(C.byref(p), C.c_int32(world_size), _ip(owner))
+    if rc != 0:
+        raise MibaError("miba_plan_point_owner rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
+    return owner
 
 
 class Solver:

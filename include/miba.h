@@ -228,6 +228,10 @@ int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid
                      int64_t* n_tiles, int64_t* n_slots, int64_t* tiles_per_rank,
                      int64_t* obs_per_rank);
 
+/* Host-only: rank that owns each of the caller's points under the same plan (-1 = point has no
+ * valid observation and is not part of the problem). owner has n_pt entries. */
+int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* owner);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,134 @@
+"""CPU tests of the host side of libmiba: the C-ABI library loads and exports every symbol that
+include/miba.h declares, fails loudly without a GPU, and the tiler / sharder (miba_plan_*) keeps its
+invariants.  No compute entry point is called here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import miba, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "miba.h")).read()
+    declared = set(re.findall(r"\b(miba_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"miba_iteration_callback"}
+    assert declared == set(miba.EXPORTS), declared ^ set(miba.EXPORTS)
+    lib = miba.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(miba.MibaError) as e:
+        miba.Solver()
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_default_options_are_ceres_defaults():
+    o = miba.default_options()
+    assert (o.max_num_iterations, o.linear_solver_type, o.jacobi_scaling) == (50, miba.ITERATIVE_SCHUR, 1)
+    assert (o.max_linear_solver_iterations, o.min_linear_solver_iterations, o.max_num_consecutive_invalid_steps) == (500, 0, 5)
+    assert (o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius) == (1e4, 1e16, 1e-32)
+    assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance, o.eta) == (1e-6, 1e-10, 1e-8, 1e-1)
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_plan_invariants(world):
+    pr = synth.make_problem(60, 5000, 26000, seed=2, shuffle_obs=True)
+    oc, op, oxy = pr["obs_cam"].copy(), pr["obs_pt"].copy(), pr["obs_xy"].copy()
+    op[3] = -1
+    oxy[10, 0] = np.nan
+    info = miba.plan_shards(60, 5000, oc, op, oxy, world)
+    assert info["n_valid"] == 26000 - 2
+    assert info["n_slots"] % 256 == 0 and info["n_slots"] >= info["n_valid"]
+    assert info["n_slots"] <= 1.25 * info["n_valid"] + 256 * 8        # padding stays small
+    assert sum(info["tiles_per_rank"]) == info["n_tiles"]
+    assert sum(info["obs_per_rank"]) == info["n_valid"]
+    mean = info["n_valid"] / world
+    assert max(info["obs_per_rank"]) <= 1.1 * mean + 1024              # shards balanced by observations
+    owner = miba.plan_point_owner(60, 5000, oc, op, oxy, world)
+    assert owner.min() >= 0 and owner.max() == world - 1
+    keep = (op != -1) & ~np.isnan(oxy[:, 0])
+    per_rank = np.bincount(owner[op[keep]], minlength=world)
+    assert per_rank.tolist() == info["obs_per_rank"]                  # a point's observations never split
+
+
+def test_plan_handles_giant_and_empty():
+    # a point seen by 700 cameras (more than a chunk), a point with no observation, unused cameras
+    n_cam, n_pt = 800, 6
+    oc = np.concatenate([np.arange(700), [0, 1, 2], [5, 6]]).astype(np.int32)
+    op = np.concatenate([np.zeros(700), [1, 1, 1], [3, 3]]).astype(np.int32)
+    oxy = np.zeros((oc.size, 2))
+    info = miba.plan_shards(n_cam, n_pt, oc, op, oxy, 2)
+    assert info["n_valid"] == 705 and info["n_slots"] == 256 * 4
+    owner = miba.plan_point_owner(n_cam, n_pt, oc, op, oxy, 2)
+    assert owner[2] == -1 and owner[4] == -1 and owner[5] == -1 and owner[0] >= 0
+
+
+def test_plan_rejects_bad_indices():
+    oc = np.array([0, 7], dtype=np.int32)
+    op = np.array([0, 0], dtype=np.int32)
+    with pytest.raises(miba.MibaError):
+        miba.plan_shards(3, 2, oc, op, np.zeros((2, 2)), 1)
+
+
+_GLOO_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from bundle_adjustment_amd import miba, synth
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+pr = synth.make_problem(30, 2000, 9000, seed=6, shuffle_obs=True)
+cams0, pts0 = synth.perturb(pr, 0.01, 0.1, seed=7)
+owner = miba.plan_point_owner(30, 2000, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], world)
+mine = owner[pr["obs_pt"]] == rank
+# every rank evaluates only the observations of the points it owns (cameras replicated) ...
+ev = O.evaluate(cams0, pts0, pr["obs_cam"][mine], pr["obs_pt"][mine], pr["obs_xy"][mine])
+col2 = np.zeros((30, 9))
+np.add.at(col2, pr["obs_cam"][mine], (ev["Jc"] ** 2).sum(1))
+buf = torch.from_numpy(np.concatenate([[ev["cost"]], ev["grad_cam"].ravel(), col2.ravel()]))
+# ... and camera-sized quantities are completed by ONE all-reduce (what RCCL does on the GPUs)
+dist.all_reduce(buf)
+full = O.evaluate(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+col2_full = np.zeros((30, 9))
+np.add.at(col2_full, pr["obs_cam"], (full["Jc"] ** 2).sum(1))
+got = buf.numpy()
+assert abs(got[0] - full["cost"]) <= 1e-12 * full["cost"]
+assert np.abs(got[1:271] - full["grad_cam"].ravel()).max() <= 1e-12 * np.abs(full["grad_cam"]).max()
+assert np.abs(got[271:] - col2_full.ravel()).max() <= 1e-12 * col2_full.max()
+# point-sized quantities never leave their rank: the local point gradient is already complete
+own_pts = owner == rank
+assert np.abs(ev["grad_pt"][own_pts] - full["grad_pt"][own_pts]).max() <= 1e-12 * np.abs(full["grad_pt"]).max()
+assert np.all(ev["grad_pt"][~own_pts] == 0.0)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+"""
+
+
+def test_point_sharding_world2_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): the sharding rule of miba_plan (points and their observations owned
+    by one rank, cameras replicated, one all-reduce of camera-sized vectors) reproduces the
+    single-process result."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
