@@ -1,0 +1,44 @@
+// Problem API, same surface as /root/reference/include/bundleadjust/BundleAdjustment.h:13-39.
+// ceres::Problem / ceres::Solve are replaced by a libmiba handle (include/miba.h).
+#pragma once
+
+#include <string>
+
+#include <ceres/ceres.h>
+
+#include "Dataloader.h"
+
+class MeshWriterCallback;
+struct miba_handle_s;
+
+class BundleAdjustment {
+public:
+    BundleAdjustment(Dataloader* dataset, ceres::Solver::Options options);
+    virtual ~BundleAdjustment();
+
+    void createProblem();
+    void solve();
+
+    double* getRotation(size_t cameraIndex);
+    double* getTranslation(size_t cameraIndex);
+    double* getIntrinsics(size_t cameraIndex);
+    double* getPoint(size_t pointIndex);
+
+    void WriteToPLYFile(std::string filename);
+
+    Dataloader* dataset;
+
+    // result of the last solve() (the reference only prints it, src/BundleAdjustment.cpp:110)
+    const ceres::Solver::Summary& lastSummary() const { return summary; }
+
+private:
+    ceres::Solver::Options options;
+    miba_handle_s* problem;   // device-resident problem (was ceres::Problem)
+    ceres::Solver::Summary summary;
+
+    double *R;
+    double *X;
+    double *T;
+    double *intrinsics;
+    MeshWriterCallback *callback;
+};

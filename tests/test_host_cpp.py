@@ -1,0 +1,103 @@
+"""The C++ host mirror of the reference's classes (include/bundleadjust, bundle_adjustment_amd/host):
+BalDataloader and BAConstraint on the CPU, BundleAdjustment + app/main.cpp end to end on the GPU."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "app", "ba_functor_check")
+MAIN = os.path.join(ROOT, "app", "ba_main")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    m = np.abs(b).max()
+    return np.abs(a - b).max() / (m if m > 0 else 1.0)
+
+
+def test_baconstraint_autodiff_matches_mpmath():
+    """BAConstraint::create(...) -> AutoDiffCostFunction<BAConstraint,2,3,3,3,6> (the reference's
+    construction, src/BAConstraint.cpp:82-86) evaluated with dual numbers, against the fixtures.
+    Autodiff differentiates (1 - cos) literally, so tiny-but-not-small angles get 1e-9 here."""
+    g = json.load(open(os.path.join(GOLD, "proj_golden.json")))
+    lines = []
+    for c in g["cases"]:
+        lines.append(" ".join(c["cam_hex"] + c["X_hex"] + c["obs_hex"]))
+    out = subprocess.run([CHECK], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0
+    rows = [[float.fromhex(t) for t in ln.split()] for ln in out.stdout.strip().split("\n")]
+    assert len(rows) == len(g["cases"])
+    for row, c in zip(rows, g["cases"]):
+        R = np.array([float(v) for v in c["r"]])
+        JC = np.array([[float(v) for v in r_] for r_ in c["Jc"]])
+        JP = np.array([[float(v) for v in r_] for r_ in c["Jp"]])
+        obs = np.array([float.fromhex(h) for h in c["obs_hex"]])
+        r = np.array(row[0:2]); jc = np.array(row[2:20]).reshape(2, 9); jp = np.array(row[20:26]).reshape(2, 3)
+        theta = np.linalg.norm([float.fromhex(h) for h in c["cam_hex"][:3]])
+        tol = 1e-10 if (c["small_angle"] or theta > 1e-3) else 1e-6
+        assert np.abs(r - R).max() / max(1.0, np.abs(R + obs).max()) <= 1e-12
+        for a, b in [(jc[:, 0:3], JC[:, 0:3]), (jc[:, 3:6], JC[:, 3:6]), (jc[:, 6:], JC[:, 6:]), (jp, JP)]:
+            assert rel(a, b) <= tol
+
+
+def test_bal_loader_parses_as_float_and_initializes(tmp_path, oracle):
+    """Text -> float (src/BalDataloader.cpp:32-33,44-45,55-56) -> double; initialize() = the
+    glibc-rand noise restated in the oracle (same libc here, seed 1 = unseeded)."""
+    pr = synth.make_problem(5, 12, 34, seed=1)
+    # un-rounded scalars in the file: the loader must round them through float
+    rng = np.random.default_rng(0)
+    raw = dict(pr)
+    raw["cams"] = pr["cams"] + rng.normal(0, 1e-9, pr["cams"].shape)
+    raw["pts"] = pr["pts"] + rng.normal(0, 1e-9, pr["pts"].shape)
+    raw["obs_xy"] = pr["obs_xy"] + rng.normal(0, 1e-7, pr["obs_xy"].shape)
+    path = str(tmp_path / "problem-5-12-pre.txt")
+    synth.write_bal(path, raw)
+    out = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    tok = out.stdout.split("\n")
+    assert tok[0].split() == ["5", "12", "34"]
+    for i in range(34):
+        c, p, x, y = tok[1 + i].split()
+        assert (int(c), int(p)) == (pr["obs_cam"][i], pr["obs_pt"][i])
+        assert float.fromhex(x) == float(np.float32(raw["obs_xy"][i, 0])) and float.fromhex(y) == float(np.float32(raw["obs_xy"][i, 1]))
+    vals = np.array([float.fromhex(t) for t in tok[35:35 + 15 + 15 + 30 + 36]])
+    R, T, K, X = oracle.bal_initialize(raw["cams"].astype(np.float32), raw["pts"].astype(np.float32), 0.01, 2.0, seed=1)
+    assert np.array_equal(vals[0:15], R.ravel()) and np.array_equal(vals[15:30], T.ravel())
+    assert np.array_equal(vals[30:60], K.ravel()) and np.array_equal(vals[60:96], X.ravel())
+    assert tok[35 + 96].split() == ["255", "255", "255", "0", "0", "1"]
+
+
+def test_bal_loader_throws_on_missing_file():
+    out = subprocess.run([CHECK, "--loader", "/nonexistent/problem.txt"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 3 and "File could not be opened" in out.stdout
+
+
+@pytest.mark.gpu
+def test_app_main_end_to_end(tmp_path, oracle):
+    """app/main.cpp: BalDataloader -> BundleAdjustment(ctor, createProblem, solve, WriteToPLYFile)
+    on the GPU, final cost against the oracle started from the same (glibc-noise) state."""
+    pr = synth.make_problem(20, 600, 2600, seed=5)
+    path = str(tmp_path / "problem-20-600-pre.txt")
+    synth.write_bal(path, pr)
+    env = dict(os.environ, BA_SIGMA_CAM="0.005", BA_SIGMA_X="0.05", BA_ITERATION_PLY="1")
+    out = subprocess.run([MAIN, path, "SPARSE_SCHUR", "10"], capture_output=True, text=True, timeout=120, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    m = re.search(r"FINAL_COST (\S+) ITERATIONS (\d+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    final = float(m.group(1))
+    R, T, K, X = oracle.bal_initialize(pr["cams"].astype(np.float32), pr["pts"].astype(np.float32), 0.005, 0.05, seed=1)
+    cams0 = np.concatenate([R, T, K[:, 0:1], K[:, 4:5], K[:, 5:6]], 1)
+    _, _, oits, osumm = oracle.solve(cams0, X, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"],
+                                     oracle.default_options(max_num_iterations=10, linear_solver=oracle.DENSE_SCHUR))
+    assert abs(final - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"], (final, osumm)
+    # the reference writes one PLY per iteration (iteration -1 included) plus the final one
+    assert os.path.exists(tmp_path / "mesh_SPARSE_SCHUR_-1.ply") and os.path.exists(tmp_path / "constrainTransReal.ply")
+    head = open(tmp_path / "constrainTransReal.ply").read().split("\n")
+    assert head[0] == "ply" and head[2] == "element vertex %d" % (600 + 20)
+    assert head[10].endswith(" 0 255 0") and "Solver Summary" in out.stdout
