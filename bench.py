@@ -162,8 +162,10 @@ def main():
         t_cpu = sum(r["iteration_time_s"] for r in oits[1:])
         n_cpu = len(oits) - 1
         same = [abs(a["cost"] - b["cost"]) / b["cost"] for a, b in zip(its[1:1 + n_cpu], oits[1:])]
+        t_gpu_same = sum(r["iteration_time_in_seconds"] for r in its[1:1 + n_cpu])
         out["cpu_baseline"] = {"value": n_cpu / t_cpu if t_cpu > 0 else None, "unit": "LM iterations/s", "cores": cores,
                                "kind": "port",
+                               "hip_value_on_same_sample": n_cpu / t_gpu_same if t_gpu_same > 0 else None,
                                "sample": "first %d LM iteration(s) of the same problem and initial state (%d PCG iterations), "
                                          "oracle/ba_oracle.c with OpenMP; cost after them agrees with the HIP path to %.1e relative"
                                          % (n_cpu, sum(r["linear_solver_iterations"] for r in oits[1:]), max(same) if same else 0.0)}
