@@ -18,6 +18,7 @@
 
 #include "../../include/miba.h"
 #include "miba_kernels.hpp"
+#include "miba_mf.hpp"
 #include "miba_plan.hpp"
 
 using namespace miba;
@@ -65,6 +66,10 @@ struct miba_handle_s {
   int2* d_pt_rng = nullptr;
   uint8_t* d_cam_active = nullptr;
   double *d_oxy = nullptr, *d_cam = nullptr, *d_cam_cand = nullptr, *d_ct = nullptr, *d_sc = nullptr;
+  double *d_ct_cand = nullptr, *d_cm = nullptr;   // candidate-state camera table; matrix-free table
+  int32_t* d_giant = nullptr;                     // local ids of giant tiles
+  int32_t n_giant = 0;
+  bool use_mf = false;                            // matrix-free K3 (MIBA_MF=1)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
   double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
   double *d_slab64 = nullptr, *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
@@ -191,8 +196,9 @@ int allreduce(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
 }
 
 // ---- building blocks -----------------------------------------------------------------------
-int launch_cam_tables(miba_handle h, const double* cam) {
-  hipLaunchKernelGGL(k_cam_tables, dim3(nblk(h->n_cam, 128)), dim3(128), 0, h->st, h->n_cam, cam, h->d_ct);
+int launch_cam_tables(miba_handle h, const double* cam, bool candidate = false) {
+  hipLaunchKernelGGL(k_cam_tables, dim3(nblk(h->n_cam, 128)), dim3(128), 0, h->st, h->n_cam, cam,
+                     candidate ? h->d_ct_cand : h->d_ct, candidate ? (double*)nullptr : h->d_cm);
   HIPCHK(h, hipGetLastError());
   return MIBA_OK;
 }
@@ -214,12 +220,13 @@ int eval_jac(miba_handle h, const double* cam, const double* X, bool scaled) {
 }
 
 int eval_cost(miba_handle h, const double* cam, const double* X) {
-  int rc = launch_cam_tables(h, cam);
+  // candidate state: its camera table must not disturb the table of the current state (K3-mf reads it)
+  int rc = launch_cam_tables(h, cam, true);
   if (rc) return rc;
   if (h->n_tiles) {
     Timed t(h, MIBA_K_EVAL_COST);
     hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
-                       h->d_ocam, h->d_oxy, h->d_ct, X, nullptr, nullptr, nullptr, h->d_part_tile);
+                       h->d_ocam, h->d_oxy, h->d_ct_cand, X, nullptr, nullptr, nullptr, h->d_part_tile);
   }
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
@@ -266,6 +273,22 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
 
 // y = S x  (x, y: 9*n_cam device vectors)
 int schur_matvec(miba_handle h, const double* x, double* y) {
+  if (h->use_mf) {
+    if (h->n_tiles) {
+      Timed t(h, MIBA_K_SCHUR_MATVEC);
+      hipLaunchKernelGGL(k_mf_matvec<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
+                         h->d_grps, h->d_idx, h->d_ocam, h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc,
+                         h->d_sp, h->d_X, h->d_Cinv, x, h->d_slab9, h->d_ctl);
+      if (h->n_giant)
+        hipLaunchKernelGGL(k_mf_matvec<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
+                           h->d_idx, h->d_ocam, h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
+                           h->d_X, h->d_Cinv, x, h->d_slab9, h->d_ctl);
+    }
+    hipLaunchKernelGGL(k_cam_reduce_mf, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
+                       h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->d_ctl);
+    HIPCHK(h, hipGetLastError());
+    return allreduce(h, y, 9 * (size_t)h->n_cam, ncclSum);
+  }
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_MATVEC);
     hipLaunchKernelGGL(k_schur_matvec<0>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
@@ -645,6 +668,11 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   ALLOC(h->d_cam_row_off, nc + 1); ALLOC(h->d_pt_rng, np); ALLOC(h->d_cam_active, nc);
   ALLOC(h->d_oxy, 2 * ns);
   ALLOC(h->d_cam, 9 * nc); ALLOC(h->d_cam_cand, 9 * nc); ALLOC(h->d_ct, (size_t)kCamTabStride * nc); ALLOC(h->d_sc, 9 * nc);
+  ALLOC(h->d_ct_cand, (size_t)kCamTabStride * nc); ALLOC(h->d_cm, 10 * nc);
+  std::vector<int32_t> giant;
+  for (size_t i = 0; i < tiles.size(); ++i) if (tiles[i].giant) giant.push_back((int32_t)i);
+  h->n_giant = (int32_t)giant.size();
+  ALLOC(h->d_giant, giant.size());
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   ALLOC(h->d_J, (size_t)kJComp * ns);
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
@@ -667,6 +695,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   UP(h->d_pt_rng, pt_rng.data(), np);
   UP(h->d_cam_active, P.cam_active.data(), nc);
   UP(h->d_oxy, oxy.data(), 2 * ns);
+  UP(h->d_giant, giant.data(), giant.size());
 #undef ALLOC
 #undef UP
   HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
@@ -678,6 +707,10 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   std::vector<int32_t>().swap(P.idx);
   std::vector<int32_t>().swap(P.ocam);
   h->has_problem = true;
+  {
+    const char* mf = getenv("MIBA_MF");
+    h->use_mf = mf && mf[0] == '1';
+  }
   memset(&h->kt, 0, sizeof(h->kt));
   return miba_set_state(h, p->R, p->T, p->K, p->X);
 }

@@ -71,7 +71,8 @@ __device__ __forceinline__ double block_max(double v, double* s4) {
 // K0: per-camera table  [R 0..8 | t 9..11 | f k1 k2 12..14 | - | dR_0 16..24 | dR_1 25..33 | dR_2 34..42]
 // R row-major; dR_j = dR/dw_j (row-major).  Branches as ceres/rotation.h.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_cam_tables(int n_cam, const double* __restrict__ cam /*[n][9]*/, double* __restrict__ ct) {
+__global__ void k_cam_tables(int n_cam, const double* __restrict__ cam /*[n][9]*/, double* __restrict__ ct,
+                             double* __restrict__ cm /*[n][10] or null*/) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cam) return;
   const double* p = cam + 9 * (size_t)c;
@@ -118,6 +119,29 @@ __global__ void k_cam_tables(int n_cam, const double* __restrict__ cam /*[n][9]*
     dR[0 * 9 + 5] = -1.0; dR[0 * 9 + 7] = 1.0;
     dR[1 * 9 + 2] = 1.0;  dR[1 * 9 + 6] = -1.0;
     dR[2 * 9 + 1] = -1.0; dR[2 * 9 + 3] = 1.0;
+  }
+  if (cm) {
+    // d(R X)/dw = -R [X]x M with M = J_r(w) = I - a [w]x + b [w]x^2, a = (1-cos)/th^2, b = (th-sin)/th^3
+    // (closed form of the same derivative as dR_j; b by series below th = 0.1 to avoid cancellation).
+    // Small-angle branch: d(RX)/dw = -[X]x, i.e. M = I and N = I in place of R (flag = 1).
+    double* m = cm + 10 * (size_t)c;
+    if (th2 > MIBA_DBL_EPS) {
+      const double th = sqrt(th2);
+      const double s = sin(th), c_ = cos(th);
+      const double omc = (c_ > 0.0) ? s * s / (1.0 + c_) : 1.0 - c_;
+      const double a = omc / th2;
+      double b;
+      if (th < 0.1) b = 1.0 / 6.0 - th2 * (1.0 / 120.0 - th2 * (1.0 / 5040.0 - th2 * (1.0 / 362880.0 - th2 / 39916800.0)));
+      else b = (th - s) / (th2 * th);
+      // [w]x^2 = w w' - th2 I
+      m[0] = 1.0 + b * (w0 * w0 - th2); m[1] = a * w2 + b * w0 * w1;        m[2] = -a * w1 + b * w0 * w2;
+      m[3] = -a * w2 + b * w1 * w0;      m[4] = 1.0 + b * (w1 * w1 - th2);  m[5] = a * w0 + b * w1 * w2;
+      m[6] = a * w1 + b * w2 * w0;       m[7] = -a * w0 + b * w2 * w1;      m[8] = 1.0 + b * (w2 * w2 - th2);
+      m[9] = 0.0;
+    } else {
+      m[0] = 1.0; m[1] = 0.0; m[2] = 0.0; m[3] = 0.0; m[4] = 1.0; m[5] = 0.0; m[6] = 0.0; m[7] = 0.0; m[8] = 1.0;
+      m[9] = 1.0;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 9; ++i) o[i] = R[i];

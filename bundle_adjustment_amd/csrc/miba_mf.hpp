@@ -1,0 +1,265 @@
+// miba_mf.hpp — matrix-free implicit-Schur product (K3-mf).
+//
+// Same operator as k_schur_matvec<0> (ImplicitSchurComplement::RightMultiply),
+// but the Jacobian blocks are rebuilt per observation from the camera, the point and nothing
+// else: MI355X has ~10 fp64 flop per HBM byte, and a stored 2x9 + 2x3 block costs 192 bytes per
+// observation per PCG iteration.  Per observation only the 4-byte index word is read from HBM.
+//
+// Factorisation used (A = d r / d P_cam, E = A R, E' = A N with N = R, or I in the small-angle branch):
+//   F x = E' (m x X + tau) + p (d x_f + f n x_k1 + f n^2 x_k2),   m = M (sc.x)_w,  tau = N' (sc.x)_t
+//   F' w: with e' = E'' w, s = p.w :  rot = M' sum (X x e'),  tr = N sum e',  (f,k1,k2) = (sum d s, f sum n s, f sum n^2 s)
+// so per (tile, camera) only 9 raw sums are accumulated in LDS and the camera-side 3x3 transforms
+// are applied once per camera after the cross-tile reduction (k_cam_reduce_mf).
+// Column scaling (Jacobi) is applied to the vectors, not to J: F_s x = F (sc.x), F_s' w = sc.(F' w),
+// E_s y = E (sp.y).
+#pragma once
+
+#include "miba_kernels.hpp"
+
+namespace miba {
+
+constexpr int kCamLds = 25;  // odd stride: conflict-free ds_read_b64 across camera slots
+
+// [R 0..8 | t 9..11 | f k1 k2 12..14 | m 15..17 | tau 18..20 | xi 21..23 | small 24]
+__device__ __forceinline__ void mf_stage_cam(double* dst, int cam, const double* __restrict__ ct,
+                                             const double* __restrict__ cm, const double* __restrict__ sc,
+                                             const double* __restrict__ x) {
+  const double* T = ct + (size_t)kCamTabStride * cam;
+  const double* M = cm + 10 * (size_t)cam;
+  const double* s = sc + 9 * (size_t)cam;
+  const double* xv = x + 9 * (size_t)cam;
+  double xs[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) xs[k] = s[k] * xv[k];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) dst[k] = T[k];
+  const bool small = M[9] != 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dst[15 + i] = M[3 * i] * xs[0] + M[3 * i + 1] * xs[1] + M[3 * i + 2] * xs[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    dst[18 + i] = small ? xs[3 + i] : (T[i] * xs[3] + T[3 + i] * xs[4] + T[6 + i] * xs[5]);  // N' x_t
+  dst[21] = xs[6]; dst[22] = xs[7]; dst[23] = xs[8];
+  dst[24] = small ? 1.0 : 0.0;
+}
+
+struct MfGeo {
+  double E[6];   // d r / d X       = A R   (unscaled)
+  double Ep[6];  // A N: equals E, or A in the small-angle branch
+  double px, py, n, d, f;
+};
+
+// cd: camera slot data (LDS or registers), X: point
+__device__ __forceinline__ void mf_geom(const double* cd, double x0, double x1, double x2, MfGeo& g) {
+  const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
+  const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
+  const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
+  const double f = cd[12], k1 = cd[13], k2 = cd[14];
+  const double iz = 1.0 / P2;
+  const double px = -P0 * iz, py = -P1 * iz;
+  const double n = px * px + py * py;
+  const double d = 1.0 + n * (k1 + k2 * n);
+  const double gg = k1 + 2.0 * k2 * n;
+  const double m00 = f * (d + 2.0 * gg * px * px), m01 = f * (2.0 * gg * px * py), m11 = f * (d + 2.0 * gg * py * py);
+  const double q0 = P0 * iz * iz, q1 = P1 * iz * iz;
+  double A[6];
+  A[0] = -m00 * iz; A[1] = -m01 * iz; A[2] = m00 * q0 + m01 * q1;
+  A[3] = -m01 * iz; A[4] = -m11 * iz; A[5] = m01 * q0 + m11 * q1;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    g.E[j] = A[0] * cd[j] + A[1] * cd[3 + j] + A[2] * cd[6 + j];
+    g.E[3 + j] = A[3] * cd[j] + A[4] * cd[3 + j] + A[5] * cd[6 + j];
+  }
+  const bool small = cd[24] != 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) g.Ep[j] = small ? A[j] : g.E[j];
+  g.px = px; g.py = py; g.n = n; g.d = d; g.f = f;
+}
+
+// u = F_s x for this observation
+__device__ __forceinline__ void mf_forward(const MfGeo& g, const double* cd, double x0, double x1, double x2, double& u0,
+                                           double& u1) {
+  // v = m x X + tau
+  const double v0 = cd[16] * x2 - cd[17] * x1 + cd[18];
+  const double v1 = cd[17] * x0 - cd[15] * x2 + cd[19];
+  const double v2 = cd[15] * x1 - cd[16] * x0 + cd[20];
+  const double si = g.d * cd[21] + g.f * g.n * (cd[22] + g.n * cd[23]);
+  u0 = g.Ep[0] * v0 + g.Ep[1] * v1 + g.Ep[2] * v2 + g.px * si;
+  u1 = g.Ep[3] * v0 + g.Ep[4] * v1 + g.Ep[5] * v2 + g.py * si;
+}
+
+// raw camera-side sums of F' w for this observation: out[0..2] = X x e', out[3..5] = e', out[6..8] = (d s, n s, n^2 s)
+__device__ __forceinline__ void mf_transpose(const MfGeo& g, double x0, double x1, double x2, double w0, double w1, double* out) {
+  const double e0 = g.Ep[0] * w0 + g.Ep[3] * w1;
+  const double e1 = g.Ep[1] * w0 + g.Ep[4] * w1;
+  const double e2 = g.Ep[2] * w0 + g.Ep[5] * w1;
+  out[0] = x1 * e2 - x2 * e1;
+  out[1] = x2 * e0 - x0 * e2;
+  out[2] = x0 * e1 - x1 * e0;
+  out[3] = e0; out[4] = e1; out[5] = e2;
+  const double s = g.px * w0 + g.py * w1;
+  out[6] = g.d * s;
+  out[7] = g.n * s;
+  out[8] = g.n * g.n * s;
+}
+
+template <bool GIANT>
+__global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                   const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                   const int32_t* __restrict__ ocam, const int2* __restrict__ pt_rng,
+                                                   const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
+                                                   const double* __restrict__ ct, const double* __restrict__ cm,
+                                                   const double* __restrict__ sc, const double* __restrict__ sp,
+                                                   const double* __restrict__ X, const double* __restrict__ Cinv,
+                                                   const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
+                                                   const Ctl* __restrict__ ctl) {
+  __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
+  __shared__ double s_acc[GIANT ? 1 : kMaxCamSlots * 9];
+  __shared__ double s_stage[kChunk * 3];
+  __shared__ double s_y[kChunk * 3];
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  const Tile t = tiles[GIANT ? tile_list[blockIdx.x] : blockIdx.x];
+  if (!GIANT && t.giant) return;
+  const int tid = threadIdx.x;
+  if (!GIANT) {
+    if (tid < t.ncs) mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, x);
+    for (int i = tid; i < t.ncs * 9; i += kChunk) s_acc[i] = 0.0;
+    __syncthreads();
+  }
+  for (int g = 0; g < t.ngrp; ++g) {
+    const Group G = grps[t.grp0 + g];
+    if (!GIANT) {
+      // ordinary group: one chunk, whole points
+      const size_t slot = (size_t)G.chunk0 * kChunk + tid;
+      const int32_t w = idx[slot];
+      const bool valid = w >= 0;
+      const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
+      MfGeo geo;
+      double x0 = 0, x1 = 0, x2 = 0, u0 = 0, u1 = 0;
+      const double* cd = s_cam + kCamLds * cs;
+      if (valid) {
+        const double* Xp = X + 3 * (size_t)(G.pt0 + pl);
+        x0 = Xp[0]; x1 = Xp[1]; x2 = Xp[2];
+        mf_geom(cd, x0, x1, x2, geo);
+        mf_forward(geo, cd, x0, x1, x2, u0, u1);
+        s_stage[tid * 3 + 0] = geo.E[0] * u0 + geo.E[3] * u1;
+        s_stage[tid * 3 + 1] = geo.E[1] * u0 + geo.E[4] * u1;
+        s_stage[tid * 3 + 2] = geo.E[2] * u0 + geo.E[5] * u1;
+      }
+      __syncthreads();
+      if (tid < G.npt) {
+        const int p = G.pt0 + tid;
+        const int2 rg = pt_rng[p];
+        const int l0 = rg.x - G.chunk0 * kChunk;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int l = l0; l < l0 + rg.y; ++l) { a0 += s_stage[l * 3]; a1 += s_stage[l * 3 + 1]; a2 += s_stage[l * 3 + 2]; }
+        const double* ci = Cinv + 6 * (size_t)p;
+        const double* s = sp + 3 * (size_t)p;
+        a0 *= s[0]; a1 *= s[1]; a2 *= s[2];                       // E_s' u = sp .* (E' u)
+        s_y[tid * 3 + 0] = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2) * s[0];   // sp .* y3
+        s_y[tid * 3 + 1] = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2) * s[1];
+        s_y[tid * 3 + 2] = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2) * s[2];
+      }
+      __syncthreads();
+      if (valid) {
+        const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
+        const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
+        const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
+        double o[9];
+        mf_transpose(geo, x0, x1, x2, w0, w1, o);
+        double* dst = s_acc + 9 * cs;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(dst + k, o[k]);
+      }
+      __syncthreads();
+    } else {
+      // giant point: its observations span G.nchunk chunks, one camera slot (= slab row) each
+      const int p = G.pt0;
+      const double x0 = X[3 * (size_t)p], x1 = X[3 * (size_t)p + 1], x2 = X[3 * (size_t)p + 2];
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t slot = (size_t)(G.chunk0 + ch) * kChunk + tid;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        if (idx[slot] >= 0) {
+          double cd[kCamLds];
+          mf_stage_cam(cd, ocam[slot], ct, cm, sc, x);
+          MfGeo geo;
+          double u0, u1;
+          mf_geom(cd, x0, x1, x2, geo);
+          mf_forward(geo, cd, x0, x1, x2, u0, u1);
+          v0 = geo.E[0] * u0 + geo.E[3] * u1; v1 = geo.E[1] * u0 + geo.E[4] * u1; v2 = geo.E[2] * u0 + geo.E[5] * u1;
+        }
+        a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
+      }
+      const double* ci = Cinv + 6 * (size_t)p;
+      const double* s = sp + 3 * (size_t)p;
+      a0 *= s[0]; a1 *= s[1]; a2 *= s[2];
+      const double y0 = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2) * s[0];
+      const double y1 = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2) * s[1];
+      const double y2 = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2) * s[2];
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t slot = (size_t)(G.chunk0 + ch) * kChunk + tid;
+        if (idx[slot] < 0) continue;
+        double cd[kCamLds];
+        mf_stage_cam(cd, ocam[slot], ct, cm, sc, x);
+        MfGeo geo;
+        double u0, u1;
+        mf_geom(cd, x0, x1, x2, geo);
+        mf_forward(geo, cd, x0, x1, x2, u0, u1);
+        const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
+        const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
+        double o[9];
+        mf_transpose(geo, x0, x1, x2, w0, w1, o);
+        double* dst = slab + 9 * (size_t)slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[k] = o[k];
+      }
+    }
+  }
+  if (!GIANT) {
+    for (int i = tid; i < t.ncs * 9; i += kChunk) slab[9 * (size_t)slab_row[t.cam0 + i / 9] + i % 9] = s_acc[i];
+  }
+}
+
+// Per camera: sum the raw slab rows in row order, then apply the camera-side transforms:
+//   out = diag_w * Dc2 .* x + sc .* [ M' c ; N a ; i_f ; f i_k1 ; f i_k2 ]
+__global__ __launch_bounds__(256) void k_cam_reduce_mf(int n_cam, const int32_t* __restrict__ cam_row_off,
+                                                       const double* __restrict__ slab, const double* __restrict__ ct,
+                                                       const double* __restrict__ cm, const double* __restrict__ sc,
+                                                       const double* __restrict__ d2, const double* __restrict__ x,
+                                                       double diag_w, double* __restrict__ out, const Ctl* __restrict__ ctl) {
+  if (ctl->done) return;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_cam) return;
+  const int lane = threadIdx.x & 63;
+  const int r0 = cam_row_off[c], r1 = cam_row_off[c + 1];
+  const int sub = lane / 9, k = lane % 9;
+  double acc = 0.0;
+  if (lane < 63)
+    for (int r = r0 + sub; r < r1; r += 7) acc += slab[9 * (size_t)r + k];
+  double tot = acc;
+#pragma unroll
+  for (int s = 1; s < 7; ++s) tot += __shfl(acc, k + 9 * s, 64);
+  // broadcast the 9 totals (held by lanes 0..8) to every lane
+  double v[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) v[j] = __shfl(tot, j, 64);
+  if (lane < 9) {
+    const double* T = ct + (size_t)kCamTabStride * c;
+    const double* M = cm + 10 * (size_t)c;
+    const bool small = M[9] != 0.0;
+    double r;
+    if (lane < 3) r = M[lane] * v[0] + M[3 + lane] * v[1] + M[6 + lane] * v[2];                       // (M' c)_lane
+    else if (lane < 6) {
+      const int i = lane - 3;
+      r = small ? v[3 + i] : (T[3 * i] * v[3] + T[3 * i + 1] * v[4] + T[3 * i + 2] * v[5]);           // (N a)_i
+    } else if (lane == 6) r = v[6];
+    else r = T[12] * v[lane];
+    r *= sc[9 * (size_t)c + lane];
+    if (d2) r += diag_w * d2[9 * (size_t)c + lane] * x[9 * (size_t)c + lane];
+    out[9 * (size_t)c + lane] = r;
+  }
+}
+
+}  // namespace miba
