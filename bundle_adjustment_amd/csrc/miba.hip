@@ -66,7 +66,7 @@ struct miba_handle_s {
   int2* d_pt_rng = nullptr;
   uint8_t* d_cam_active = nullptr;
   double *d_oxy = nullptr, *d_cam = nullptr, *d_cam_cand = nullptr, *d_ct = nullptr, *d_sc = nullptr;
-  double *d_ct_cand = nullptr, *d_cm = nullptr;   // candidate-state camera table; matrix-free table
+  double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
   int32_t n_giant = 0;
   bool use_mf = false;                            // matrix-free K3 (MIBA_MF=1)
@@ -244,7 +244,7 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
     Timed t(h, MIBA_K_SCHUR_INIT);
     hipLaunchKernelGGL(k_schur_init, dim3((unsigned)h->n_tiles), dim3(kChunk), kK2Lds, h->st, h->d_tiles, h->d_grps, h->d_idx,
                        h->d_pt_rng, h->d_slab_row, h->d_J, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp,
-                       h->d_dgp, h->d_slab64, h->d_ctl);
+                       h->d_dgp, h->d_slab64, h->d_ctl, h->d_X, h->d_sp, h->d_ptrec);
   }
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab64,
@@ -278,11 +278,11 @@ int schur_matvec(miba_handle h, const double* x, double* y) {
       Timed t(h, MIBA_K_SCHUR_MATVEC);
       hipLaunchKernelGGL(k_mf_matvec<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
                          h->d_grps, h->d_idx, h->d_ocam, h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc,
-                         h->d_sp, h->d_X, h->d_Cinv, x, h->d_slab9, h->d_ctl);
+                         h->d_sp, h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, h->d_ctl);
       if (h->n_giant)
         hipLaunchKernelGGL(k_mf_matvec<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
                            h->d_idx, h->d_ocam, h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
-                           h->d_X, h->d_Cinv, x, h->d_slab9, h->d_ctl);
+                           h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, h->d_ctl);
     }
     hipLaunchKernelGGL(k_cam_reduce_mf, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
                        h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->d_ctl);
@@ -668,7 +668,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   ALLOC(h->d_cam_row_off, nc + 1); ALLOC(h->d_pt_rng, np); ALLOC(h->d_cam_active, nc);
   ALLOC(h->d_oxy, 2 * ns);
   ALLOC(h->d_cam, 9 * nc); ALLOC(h->d_cam_cand, 9 * nc); ALLOC(h->d_ct, (size_t)kCamTabStride * nc); ALLOC(h->d_sc, 9 * nc);
-  ALLOC(h->d_ct_cand, (size_t)kCamTabStride * nc); ALLOC(h->d_cm, 10 * nc);
+  ALLOC(h->d_ct_cand, (size_t)kCamTabStride * nc); ALLOC(h->d_cm, 10 * nc); ALLOC(h->d_ptrec, 10 * np);
   std::vector<int32_t> giant;
   for (size_t i = 0; i < tiles.size(); ++i) if (tiles[i].giant) giant.push_back((int32_t)i);
   h->n_giant = (int32_t)giant.size();

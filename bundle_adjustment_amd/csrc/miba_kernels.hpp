@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ til
                                                     double inv_radius, double dmin, double dmax,
                                                     double* __restrict__ Cinv /*[npt][6]*/, double* __restrict__ gp /*[npt][3]*/,
                                                     double* __restrict__ dgp /*[npt][3] diag E'E*/,
-                                                    double* __restrict__ slab /*[nrows][64]*/, Ctl* __restrict__ ctl) {
+                                                    double* __restrict__ slab /*[nrows][64]*/, Ctl* __restrict__ ctl,
+                                                    const double* __restrict__ X, const double* __restrict__ sp,
+                                                    double* __restrict__ ptrec /*[npt][10]: X, sp C^-1 sp, range*/) {
   extern __shared__ double lds[];
   double* s_acc = lds;                              // [kMaxCamSlots][63]  (stride 63: odd => fewer bank conflicts)
   double* s_stage = lds + kMaxCamSlots * 63;        // [256][9]
@@ -355,6 +357,15 @@ __global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ til
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) Cinv[6 * (size_t)p + k] = ci[k];
+        {
+          // per-point record of the matrix-free product: X, diag(sp) C^-1 diag(sp), slot range in the chunk
+          double* rp = ptrec + 10 * (size_t)p;
+          const double s0 = sp[3 * (size_t)p], s1 = sp[3 * (size_t)p + 1], s2 = sp[3 * (size_t)p + 2];
+          rp[0] = X[3 * (size_t)p]; rp[1] = X[3 * (size_t)p + 1]; rp[2] = X[3 * (size_t)p + 2];
+          rp[3] = s0 * ci[0] * s0; rp[4] = s1 * ci[1] * s0; rp[5] = s1 * ci[2] * s1;
+          rp[6] = s2 * ci[3] * s0; rp[7] = s2 * ci[4] * s1; rp[8] = s2 * ci[5] * s2;
+          rp[9] = __longlong_as_double((long long)(l0 | (rg.y << 16)));
+        }
         gp[3 * (size_t)p] = a[6]; gp[3 * (size_t)p + 1] = a[7]; gp[3 * (size_t)p + 2] = a[8];
         s_y[tid * 3 + 0] = ci[0] * a[6] + ci[1] * a[7] + ci[3] * a[8];
         s_y[tid * 3 + 1] = ci[1] * a[6] + ci[2] * a[7] + ci[4] * a[8];

@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
                                                    const double* __restrict__ ct, const double* __restrict__ cm,
                                                    const double* __restrict__ sc, const double* __restrict__ sp,
                                                    const double* __restrict__ X, const double* __restrict__ Cinv,
+                                                   const double* __restrict__ ptrec /*[npt][10]*/,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
                                                    const Ctl* __restrict__ ctl) {
+  __shared__ double s_X[GIANT ? 1 : kChunk * 3];
   __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
   __shared__ double s_acc[GIANT ? 1 : kMaxCamSlots * 9];
   __shared__ double s_stage[kChunk * 3];
@@ -130,40 +132,45 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
   for (int g = 0; g < t.ngrp; ++g) {
     const Group G = grps[t.grp0 + g];
     if (!GIANT) {
-      // ordinary group: one chunk, whole points
+      // ordinary group: one chunk, whole points.  All global loads of the chunk (index word per
+      // observation, one 80-byte record per point) are issued up front: one memory latency per chunk.
       const size_t slot = (size_t)G.chunk0 * kChunk + tid;
       const int32_t w = idx[slot];
+      double rec[10];
+      if (tid < G.npt) {
+        const double* rp = ptrec + 10 * (size_t)(G.pt0 + tid);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) rec[k] = rp[k];
+        s_X[tid] = rec[0]; s_X[kChunk + tid] = rec[1]; s_X[2 * kChunk + tid] = rec[2];
+      }
       const bool valid = w >= 0;
       const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
+      __syncthreads();
       MfGeo geo;
       double x0 = 0, x1 = 0, x2 = 0, u0 = 0, u1 = 0;
       const double* cd = s_cam + kCamLds * cs;
       if (valid) {
-        const double* Xp = X + 3 * (size_t)(G.pt0 + pl);
-        x0 = Xp[0]; x1 = Xp[1]; x2 = Xp[2];
+        x0 = s_X[pl]; x1 = s_X[kChunk + pl]; x2 = s_X[2 * kChunk + pl];
         mf_geom(cd, x0, x1, x2, geo);
         mf_forward(geo, cd, x0, x1, x2, u0, u1);
-        s_stage[tid * 3 + 0] = geo.E[0] * u0 + geo.E[3] * u1;
-        s_stage[tid * 3 + 1] = geo.E[1] * u0 + geo.E[4] * u1;
-        s_stage[tid * 3 + 2] = geo.E[2] * u0 + geo.E[5] * u1;
+        s_stage[tid] = geo.E[0] * u0 + geo.E[3] * u1;
+        s_stage[kChunk + tid] = geo.E[1] * u0 + geo.E[4] * u1;
+        s_stage[2 * kChunk + tid] = geo.E[2] * u0 + geo.E[5] * u1;
       }
       __syncthreads();
       if (tid < G.npt) {
-        const int p = G.pt0 + tid;
-        const int2 rg = pt_rng[p];
-        const int l0 = rg.x - G.chunk0 * kChunk;
+        const int bits = (int)__double_as_longlong(rec[9]);
+        const int l0 = bits & 0xFFFF, cnt = bits >> 16;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int l = l0; l < l0 + rg.y; ++l) { a0 += s_stage[l * 3]; a1 += s_stage[l * 3 + 1]; a2 += s_stage[l * 3 + 2]; }
-        const double* ci = Cinv + 6 * (size_t)p;
-        const double* s = sp + 3 * (size_t)p;
-        a0 *= s[0]; a1 *= s[1]; a2 *= s[2];                       // E_s' u = sp .* (E' u)
-        s_y[tid * 3 + 0] = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2) * s[0];   // sp .* y3
-        s_y[tid * 3 + 1] = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2) * s[1];
-        s_y[tid * 3 + 2] = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2) * s[2];
+        for (int l = l0; l < l0 + cnt; ++l) { a0 += s_stage[l]; a1 += s_stage[kChunk + l]; a2 += s_stage[2 * kChunk + l]; }
+        // rec[3..8] = diag(sp) C^-1 diag(sp): y = sp .* (-C^-1 (sp .* a))
+        s_y[tid] = -(rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
+        s_y[kChunk + tid] = -(rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
+        s_y[2 * kChunk + tid] = -(rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
       }
       __syncthreads();
       if (valid) {
-        const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
+        const double y0 = s_y[pl], y1 = s_y[kChunk + pl], y2 = s_y[2 * kChunk + pl];
         const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
         const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
         double o[9];
@@ -172,7 +179,6 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
 #pragma unroll
         for (int k = 0; k < 9; ++k) atomicAdd(dst + k, o[k]);
       }
-      __syncthreads();
     } else {
       // giant point: its observations span G.nchunk chunks, one camera slot (= slab row) each
       const int p = G.pt0;
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
     }
   }
   if (!GIANT) {
+    __syncthreads();  // every wave's LDS atomics have landed
     for (int i = tid; i < t.ncs * 9; i += kChunk) slab[9 * (size_t)slab_row[t.cam0 + i / 9] + i % 9] = s_acc[i];
   }
 }

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -19,7 +20,7 @@ namespace miba {
 
 constexpr int kChunk = 256;        // observation slots per chunk = threads per block
 constexpr int kMaxCamSlots = 96;   // distinct cameras per (non-giant) tile: LDS accumulator rows
-constexpr int kMaxChunksPerTile = 4;
+constexpr int kMaxChunksPerTile = 4;   // default; MIBA_TILE_CHUNKS overrides (1..16)
 constexpr int kJComp = 26;         // doubles stored per observation: F 18, E 6, r 2
 constexpr int kCamTabStride = 48;  // per-camera table row (R 9, t 3, f k1 k2, pad, dR 27, pad)
 
@@ -66,6 +67,8 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   P.n_cam = n_cam; P.n_pt_in = n_pt; P.n_obs_in = n_obs;
   if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || world_size < 1) return -1;
   if (n_cam >= (1 << 24)) return -6;
+  int max_chunks = kMaxChunksPerTile;
+  if (const char* e = getenv("MIBA_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 16) max_chunks = v; }
   // --- filter (src/BundleAdjustment.cpp:49-60) and count
   std::vector<int32_t> cnt(n_pt, 0);
   std::vector<int32_t> mincam(n_pt, INT32_MAX);
@@ -188,7 +191,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     }
     if (tile_open && chunk_open && (chunk_fill + L > kChunk || G.npt >= 256)) {
       close_chunk();
-      if (T.ngrp >= kMaxChunksPerTile) close_tile();
+      if (T.ngrp >= max_chunks) close_tile();
     }
     if (!tile_open) open_tile(0);
     if (!chunk_open) open_chunk(s);
