@@ -64,6 +64,7 @@ struct miba_handle_s {
   Tile* d_tiles = nullptr; Group* d_grps = nullptr;
   int32_t *d_idx = nullptr, *d_ocam = nullptr, *d_tile_cams = nullptr, *d_slab_row = nullptr, *d_cam_row_off = nullptr;
   int2* d_pt_rng = nullptr;
+  int2* d_wl = nullptr;   // per 64-slot wavelet: {first point, number of points}
   uint8_t* d_cam_active = nullptr;
   double *d_oxy = nullptr, *d_cam = nullptr, *d_cam_cand = nullptr, *d_ct = nullptr, *d_sc = nullptr;
   double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
@@ -277,11 +278,11 @@ int schur_matvec(miba_handle h, const double* x, double* y) {
     if (h->n_tiles) {
       Timed t(h, MIBA_K_SCHUR_MATVEC);
       hipLaunchKernelGGL(k_mf_matvec<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
-                         h->d_grps, h->d_idx, h->d_ocam, h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc,
+                         h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc,
                          h->d_sp, h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, h->d_ctl);
       if (h->n_giant)
         hipLaunchKernelGGL(k_mf_matvec<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
-                           h->d_idx, h->d_ocam, h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
+                           h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
                            h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, h->d_ctl);
     }
     hipLaunchKernelGGL(k_cam_reduce_mf, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
@@ -647,6 +648,11 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     oxy[chunk * 2 * kChunk + kChunk + lane] = p->obs_xy[2 * o + 1];
     h->n_obs_local++;
   }
+  std::vector<int2> wlv((size_t)(h->n_slots / kWave) + 1);
+  for (int64_t q = 0; q < h->n_slots / kWave; ++q) {
+    wlv[q].x = P.wl_pt0[h->slot_base / kWave + q] - h->pt_base;
+    wlv[q].y = P.wl_npt[h->slot_base / kWave + q];
+  }
   std::vector<int2> pt_rng(h->n_pt ? h->n_pt : 1);
   for (int32_t q = 0; q < h->n_pt; ++q) {
     pt_rng[q].x = P.pt_first[h->pt_base + q] - (int32_t)h->slot_base;
@@ -665,7 +671,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   const size_t nc = (size_t)p->n_cam, np = (size_t)h->n_pt, ns = (size_t)h->n_slots, nt = (size_t)h->n_tiles;
   ALLOC(h->d_tiles, nt); ALLOC(h->d_grps, grps.size());
   ALLOC(h->d_idx, ns); ALLOC(h->d_ocam, ns); ALLOC(h->d_tile_cams, n_rows); ALLOC(h->d_slab_row, n_rows);
-  ALLOC(h->d_cam_row_off, nc + 1); ALLOC(h->d_pt_rng, np); ALLOC(h->d_cam_active, nc);
+  ALLOC(h->d_cam_row_off, nc + 1); ALLOC(h->d_pt_rng, np); ALLOC(h->d_cam_active, nc); ALLOC(h->d_wl, wlv.size());
   ALLOC(h->d_oxy, 2 * ns);
   ALLOC(h->d_cam, 9 * nc); ALLOC(h->d_cam_cand, 9 * nc); ALLOC(h->d_ct, (size_t)kCamTabStride * nc); ALLOC(h->d_sc, 9 * nc);
   ALLOC(h->d_ct_cand, (size_t)kCamTabStride * nc); ALLOC(h->d_cm, 10 * nc); ALLOC(h->d_ptrec, 10 * np);
@@ -693,6 +699,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   UP(h->d_slab_row, slab_row.data(), n_rows);
   UP(h->d_cam_row_off, cam_row_off.data(), nc + 1);
   UP(h->d_pt_rng, pt_rng.data(), np);
+  UP(h->d_wl, wlv.data(), wlv.size());
   UP(h->d_cam_active, P.cam_active.data(), nc);
   UP(h->d_oxy, oxy.data(), 2 * ns);
   UP(h->d_giant, giant.data(), giant.size());
@@ -887,6 +894,36 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
     if (rc) return rc;
     HIPCHK(h, hipMemcpy(s_probe, h->d_pq, n * sizeof(double), hipMemcpyDeviceToHost));
   }
+  return MIBA_OK;
+}
+
+int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* avg_ms) {
+  if (!h || !h->has_problem || !probe || !avg_ms || reps < 1) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->jac_valid) return fail(h, MIBA_ERR_INVALID, "call miba_linear_step first (Jacobian / Schur blocks not set up)");
+  const size_t n = 9 * (size_t)h->n_cam;
+  HIPCHK(h, hipMemcpy(h->d_probe, probe, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemsetAsync(&h->d_ctl->done, 0, sizeof(int32_t), h->st));
+  int rc = schur_matvec(h, h->d_probe, h->d_pq);  // warm-up
+  if (rc) return rc;
+  rc = sync_stream(h);
+  if (rc) return rc;
+  hipEvent_t a, b;
+  HIPCHK(h, hipEventCreate(&a));
+  HIPCHK(h, hipEventCreate(&b));
+  HIPCHK(h, hipEventRecord(a, h->st));
+  for (int i = 0; i < reps; ++i) {
+    rc = schur_matvec(h, h->d_probe, h->d_pq);
+    if (rc) return rc;
+  }
+  HIPCHK(h, hipEventRecord(b, h->st));
+  rc = sync_stream(h);
+  if (rc) return rc;
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *avg_ms = (double)ms / reps;
   return MIBA_OK;
 }
 

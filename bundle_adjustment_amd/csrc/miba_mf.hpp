@@ -18,6 +18,7 @@
 
 namespace miba {
 
+constexpr int kAccCopies = 4;  // copies of the per-tile camera accumulators (fewer same-address LDS atomics)
 constexpr int kCamLds = 25;  // odd stride: conflict-free ds_read_b64 across camera slots
 
 // [R 0..8 | t 9..11 | f k1 k2 12..14 | m 15..17 | tau 18..20 | xi 21..23 | small 24]
@@ -103,10 +104,16 @@ __device__ __forceinline__ void mf_transpose(const MfGeo& g, double x0, double x
   out[8] = g.n * g.n * s;
 }
 
+// One wavefront = one 64-slot wavelet: a point's observations never leave their wavelet, so the
+// per-point sum of E'u is a segmented scan over lanes (shuffles) and every lane applies its point's
+// 3x3 block itself: no workgroup barrier and no LDS exchange inside the tile loop, waves of a
+// workgroup run independently and hide each other's memory latency.  The workgroup only shares the
+// per-tile camera data and the per-tile camera accumulators in LDS (one barrier after staging, one
+// before the flush).
 template <bool GIANT>
 __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
-                                                   const int32_t* __restrict__ ocam, const int2* __restrict__ pt_rng,
+                                                   const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
                                                    const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
                                                    const double* __restrict__ ct, const double* __restrict__ cm,
                                                    const double* __restrict__ sc, const double* __restrict__ sp,
@@ -114,11 +121,8 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
                                                    const double* __restrict__ ptrec /*[npt][10]*/,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
                                                    const Ctl* __restrict__ ctl) {
-  __shared__ double s_X[GIANT ? 1 : kChunk * 3];
   __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
-  __shared__ double s_acc[GIANT ? 1 : kMaxCamSlots * 9];
-  __shared__ double s_stage[kChunk * 3];
-  __shared__ double s_y[kChunk * 3];
+  __shared__ double s_acc[GIANT ? 1 : kAccCopies * kMaxCamSlots * 9];
   __shared__ double s4[4];
   if (ctl->done) return;
   const Tile t = tiles[GIANT ? tile_list[blockIdx.x] : blockIdx.x];
@@ -126,60 +130,72 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
   const int tid = threadIdx.x;
   if (!GIANT) {
     if (tid < t.ncs) mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, x);
-    for (int i = tid; i < t.ncs * 9; i += kChunk) s_acc[i] = 0.0;
+    for (int i = tid; i < kAccCopies * t.ncs * 9; i += kChunk) s_acc[i] = 0.0;
     __syncthreads();
-  }
-  for (int g = 0; g < t.ngrp; ++g) {
-    const Group G = grps[t.grp0 + g];
-    if (!GIANT) {
-      // ordinary group: one chunk, whole points.  All global loads of the chunk (index word per
-      // observation, one 80-byte record per point) are issued up front: one memory latency per chunk.
-      const size_t slot = (size_t)G.chunk0 * kChunk + tid;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int nwl = t.nslot / kWave;
+    const int acc_stride = t.ncs * 9;
+    for (int q = wv; q < nwl; q += 4) {
+      const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
       const int32_t w = idx[slot];
-      double rec[10];
-      if (tid < G.npt) {
-        const double* rp = ptrec + 10 * (size_t)(G.pt0 + tid);
-#pragma unroll
-        for (int k = 0; k < 10; ++k) rec[k] = rp[k];
-        s_X[tid] = rec[0]; s_X[kChunk + tid] = rec[1]; s_X[2 * kChunk + tid] = rec[2];
-      }
+      const int maxrun = wl[(t.slot0 >> 6) + q].y;    // longest point run in this wavelet (wave-uniform)
+      const int gpt0 = grps[t.grp0 + (q >> 2)].pt0;   // first point of the enclosing 256-slot chunk
       const bool valid = w >= 0;
       const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
-      __syncthreads();
+      const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
+      // the point's record, gathered per observation (lanes of one point read the same 72 bytes)
+      double rec[9];
+      if (valid) {
+        const double* rp = ptrec + 10 * (size_t)(gpt0 + pl);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rec[k] = rp[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rec[k] = 0.0;
+      }
       MfGeo geo;
-      double x0 = 0, x1 = 0, x2 = 0, u0 = 0, u1 = 0;
+      double u0 = 0, u1 = 0, v0 = 0, v1 = 0, v2 = 0;
       const double* cd = s_cam + kCamLds * cs;
       if (valid) {
-        x0 = s_X[pl]; x1 = s_X[kChunk + pl]; x2 = s_X[2 * kChunk + pl];
-        mf_geom(cd, x0, x1, x2, geo);
-        mf_forward(geo, cd, x0, x1, x2, u0, u1);
-        s_stage[tid] = geo.E[0] * u0 + geo.E[3] * u1;
-        s_stage[kChunk + tid] = geo.E[1] * u0 + geo.E[4] * u1;
-        s_stage[2 * kChunk + tid] = geo.E[2] * u0 + geo.E[5] * u1;
+        mf_geom(cd, rec[0], rec[1], rec[2], geo);
+        mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
+        v0 = geo.E[0] * u0 + geo.E[3] * u1;
+        v1 = geo.E[1] * u0 + geo.E[4] * u1;
+        v2 = geo.E[2] * u0 + geo.E[5] * u1;
       }
-      __syncthreads();
-      if (tid < G.npt) {
-        const int bits = (int)__double_as_longlong(rec[9]);
-        const int l0 = bits & 0xFFFF, cnt = bits >> 16;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int l = l0; l < l0 + cnt; ++l) { a0 += s_stage[l]; a1 += s_stage[kChunk + l]; a2 += s_stage[2 * kChunk + l]; }
-        // rec[3..8] = diag(sp) C^-1 diag(sp): y = sp .* (-C^-1 (sp .* a))
-        s_y[tid] = -(rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
-        s_y[kChunk + tid] = -(rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
-        s_y[2 * kChunk + tid] = -(rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
+      // segmented inclusive scan over the lanes of each point (a point's lanes are contiguous)
+      for (int d = 1; d < maxrun; d <<= 1) {
+        const double t0 = __shfl_up(v0, d, 64), t1 = __shfl_up(v1, d, 64), t2 = __shfl_up(v2, d, 64);
+        if (pos >= d) { v0 += t0; v1 += t1; v2 += t2; }
       }
-      __syncthreads();
+      // total of the run sits in its last lane
+      const int last = lane - pos + cnt - 1;
+      const double a0 = __shfl(v0, last, 64), a1 = __shfl(v1, last, 64), a2 = __shfl(v2, last, 64);
       if (valid) {
-        const double y0 = s_y[pl], y1 = s_y[kChunk + pl], y2 = s_y[2 * kChunk + pl];
+        // rec[3..8] = diag(sp) C^-1 diag(sp);  y = -that * sum E'u
+        const double y0 = -(rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
+        const double y1 = -(rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
+        const double y2 = -(rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
         const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
         const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
         double o[9];
-        mf_transpose(geo, x0, x1, x2, w0, w1, o);
-        double* dst = s_acc + 9 * cs;
+        mf_transpose(geo, rec[0], rec[1], rec[2], w0, w1, o);
+        // consecutive points go to different accumulator copies: lanes of one ds_add rarely share an address
+        double* dst = s_acc + (pl & (kAccCopies - 1)) * acc_stride + 9 * cs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) atomicAdd(dst + k, o[k]);
       }
-    } else {
+    }
+    __syncthreads();  // every wave's LDS atomics have landed
+    for (int i = tid; i < acc_stride; i += kChunk) {
+      double v = s_acc[i];
+#pragma unroll
+      for (int c = 1; c < kAccCopies; ++c) v += s_acc[c * acc_stride + i];
+      slab[9 * (size_t)slab_row[t.cam0 + i / 9] + i % 9] = v;
+    }
+  } else {
+    for (int g = 0; g < t.ngrp; ++g) {
+      const Group G = grps[t.grp0 + g];
       // giant point: its observations span G.nchunk chunks, one camera slot (= slab row) each
       const int p = G.pt0;
       const double x0 = X[3 * (size_t)p], x1 = X[3 * (size_t)p + 1], x2 = X[3 * (size_t)p + 2];
@@ -222,10 +238,6 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
         for (int k = 0; k < 9; ++k) dst[k] = o[k];
       }
     }
-  }
-  if (!GIANT) {
-    __syncthreads();  // every wave's LDS atomics have landed
-    for (int i = tid; i < t.ncs * 9; i += kChunk) slab[9 * (size_t)slab_row[t.cam0 + i / 9] + i % 9] = s_acc[i];
   }
 }
 

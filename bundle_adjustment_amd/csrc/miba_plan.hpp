@@ -19,7 +19,8 @@
 namespace miba {
 
 constexpr int kChunk = 256;        // observation slots per chunk = threads per block
-constexpr int kMaxCamSlots = 96;   // distinct cameras per (non-giant) tile: LDS accumulator rows
+constexpr int kWave = 64;          // a point never straddles a 64-slot wavelet (one wavefront)
+constexpr int kMaxCamSlots = 64;   // distinct cameras per (non-giant) tile: LDS accumulator rows
 constexpr int kMaxChunksPerTile = 4;   // default; MIBA_TILE_CHUNKS overrides (1..16)
 constexpr int kJComp = 26;         // doubles stored per observation: F 18, E 6, r 2
 constexpr int kCamTabStride = 48;  // per-camera table row (R 9, t 3, f k1 k2, pad, dR 27, pad)
@@ -54,6 +55,7 @@ struct Plan {
   std::vector<int32_t> pt_first;         // [n_pt] first slot of sorted point
   std::vector<int32_t> pt_count;         // [n_pt]
   std::vector<int32_t> tile_cams;        // per (tile, cam slot): global camera id
+  std::vector<int32_t> wl_pt0, wl_npt;   // per 64-slot wavelet: first sorted point that starts in it, longest run
   int64_t n_slots = 0;
   // sharding: rank r owns tiles [shard_tile[r], shard_tile[r+1])
   std::vector<int64_t> shard_tile;
@@ -156,8 +158,9 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   for (int32_t s = 0; s < n_act; ++s) {
     const int64_t a = off[s], b = off[s + 1];
     const int32_t L = (int32_t)(b - a);
-    if (L > kMaxCamSlots) {
-      // giant point: a tile of its own, one camera slot per observation, no LDS accumulation
+    if (L > kWave) {
+      // giant point (more observations than a wavefront): a tile of its own, one camera slot per
+      // observation, no LDS accumulation
       close_tile();
       open_tile(1);
       open_chunk(s);
@@ -189,12 +192,19 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
       }
       if (T.ncs + add > kMaxCamSlots) close_tile();
     }
-    if (tile_open && chunk_open && (chunk_fill + L > kChunk || G.npt >= 256)) {
-      close_chunk();
-      if (T.ngrp >= max_chunks) close_tile();
+    if (tile_open && chunk_open) {
+      const int pos = (int)(slots - (int64_t)G.chunk0 * kChunk);
+      const int padw = ((pos % kWave) + L > kWave) ? kWave - (pos % kWave) : 0;
+      if (pos + padw + L > kChunk || G.npt >= 256) {
+        close_chunk();
+        if (T.ngrp >= max_chunks) close_tile();
+      }
     }
     if (!tile_open) open_tile(0);
     if (!chunk_open) open_chunk(s);
+    // keep the point inside one 64-slot wavelet
+    if ((int)(slots % kWave) + L > kWave)
+      while (slots % kWave) { P.idx.push_back(-1); P.ocam.push_back(0); P.slot_orig.push_back(-1); ++slots; }
     const int32_t tid = (int32_t)P.tiles.size();
     P.pt_first[s] = (int32_t)slots;
     P.pt_count[s] = L;
@@ -207,7 +217,8 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
         slot_of[c] = T.ncs++;
         P.tile_cams.push_back(c);
       }
-      P.idx.push_back(pl | (slot_of[c] << 8));
+      // point-in-chunk | camera-slot-in-tile << 8 | position in the point's run << 16 | run length << 23
+      P.idx.push_back(pl | (slot_of[c] << 8) | ((int32_t)(j - a) << 16) | (L << 23));
       P.ocam.push_back(c);
       P.slot_orig.push_back(i);
       ++slots;
@@ -217,6 +228,13 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   }
   close_tile();
   P.n_slots = slots;
+  P.wl_pt0.assign((size_t)(slots / kWave) + 1, 0);
+  P.wl_npt.assign((size_t)(slots / kWave) + 1, 0);
+  for (int32_t s = n_act - 1; s >= 0; --s) {
+    const size_t wq = (size_t)(P.pt_first[s] / kWave);
+    P.wl_pt0[wq] = s;
+    P.wl_npt[wq] = std::max(P.wl_npt[wq], P.pt_count[s]);   // longest run in the wavelet
+  }
   // --- shard tiles by cumulative slot count
   P.shard_tile.assign(world_size + 1, 0);
   const int64_t nt = (int64_t)P.tiles.size();

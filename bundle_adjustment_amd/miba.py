@@ -21,7 +21,7 @@ EXPORTS = [
     "miba_default_options", "miba_create", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
-    "miba_plan_shards", "miba_plan_point_owner",
+    "miba_plan_shards", "miba_plan_point_owner", "miba_time_matvec",
 ]
 
 
@@ -261,6 +261,12 @@ class Solver:
         summ = {f: getattr(s, f) for f, _ in Summary._fields_}
         summ["message"] = summ["message"].decode(errors="replace")
         return recs, summ
+
+    def time_matvec(self, probe, reps=20):
+        v = np.ascontiguousarray(probe, dtype=np.float64)
+        ms = C.c_double()
+        self._chk(lib().miba_time_matvec(self._h, _dp(v), C.c_int32(reps), C.byref(ms)), "miba_time_matvec")
+        return ms.value
 
     def kernel_times(self):
         kt = KernelTimes()

@@ -219,6 +219,10 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
                      double* y_pt, double* rhs, const double* probe, double* s_probe,
                      int32_t* n_cg, double* model_cost_change);
 
+/* Measurement hook: average time of `reps` back-to-back implicit-Schur products S*probe (K3 plus its
+ * camera reduction) at the state prepared by the last miba_linear_step. probe has 9*n_cam entries. */
+int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* avg_ms);
+
 int miba_get_kernel_times(miba_handle h, miba_kernel_times* out);
 int miba_reset_kernel_times(miba_handle h);
 

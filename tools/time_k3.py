@@ -1,0 +1,17 @@
+"""Time the implicit-Schur product in isolation on a synthetic config (GPU).  usage: time_k3.py [config] [reps]"""
+import os, sys, json, numpy as np
+sys.path.insert(0, '.')
+from bundle_adjustment_amd import miba, synth
+cfg = sys.argv[1] if len(sys.argv) > 1 else "final-13682"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+n_cam, n_pt, n_obs, seed = synth.CONFIGS[cfg]
+pr = synth.make_problem(n_cam, n_pt, n_obs, seed=seed)
+cams0, pts0 = synth.perturb(pr, 1e-3, 0.05, seed=seed + 1)
+s = miba.Solver(device_id=0)
+s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+probe = np.random.default_rng(1).normal(size=(n_cam, 9))
+out = s.linear_step(1e4, miba.default_options(max_linear_solver_iterations=2), probe=probe)
+ms = [s.time_matvec(probe, reps) for _ in range(3)]
+kt = s.kernel_times()
+print(json.dumps({"mf": os.environ.get("MIBA_MF", "0"), "tile_chunks": os.environ.get("MIBA_TILE_CHUNKS", "4"), "matvec_ms": ms,
+                  "Sv_norm": float(np.linalg.norm(out["Sv"])), "slots": kt["n_slots"], "tiles": kt["n_tiles"]}))
