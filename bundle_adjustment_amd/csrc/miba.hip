@@ -70,7 +70,7 @@ struct miba_handle_s {
   double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
   int32_t n_giant = 0;
-  bool use_mf = false;                            // matrix-free K3 (MIBA_MF=1)
+  bool use_mf = true;                             // matrix-free K3 (MIBA_MF=0 turns it off)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
   double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
   double *d_slab64 = nullptr, *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
@@ -715,8 +715,8 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   std::vector<int32_t>().swap(P.ocam);
   h->has_problem = true;
   {
-    const char* mf = getenv("MIBA_MF");
-    h->use_mf = mf && mf[0] == '1';
+    const char* mf = getenv("MIBA_MF");   // matrix-free K3 is the default; MIBA_MF=0 selects the stored-Jacobian product
+    h->use_mf = !(mf && mf[0] == '0');
   }
   memset(&h->kt, 0, sizeof(h->kt));
   return miba_set_state(h, p->R, p->T, p->K, p->X);

@@ -110,6 +110,13 @@ __device__ __forceinline__ void mf_transpose(const MfGeo& g, double x0, double x
 // workgroup run independently and hide each other's memory latency.  The workgroup only shares the
 // per-tile camera data and the per-tile camera accumulators in LDS (one barrier after staging, one
 // before the flush).
+// value of v in the lane whose byte address (lane * 4) is given: two ds_bpermute_b32, no LDS storage
+__device__ __forceinline__ double lane_read(double v, int lane_byte_addr) {
+  const int lo = __builtin_amdgcn_ds_bpermute(lane_byte_addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(lane_byte_addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 template <bool GIANT>
 __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
@@ -165,12 +172,14 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
       }
       // segmented inclusive scan over the lanes of each point (a point's lanes are contiguous)
       for (int d = 1; d < maxrun; d <<= 1) {
-        const double t0 = __shfl_up(v0, d, 64), t1 = __shfl_up(v1, d, 64), t2 = __shfl_up(v2, d, 64);
-        if (pos >= d) { v0 += t0; v1 += t1; v2 += t2; }
+        const int src = (lane - d) << 2;   // byte address of the source lane (wraps harmlessly: masked by pos >= d)
+        const double t0 = lane_read(v0, src), t1 = lane_read(v1, src), t2 = lane_read(v2, src);
+        const bool in = pos >= d;
+        v0 += in ? t0 : 0.0; v1 += in ? t1 : 0.0; v2 += in ? t2 : 0.0;
       }
       // total of the run sits in its last lane
-      const int last = lane - pos + cnt - 1;
-      const double a0 = __shfl(v0, last, 64), a1 = __shfl(v1, last, 64), a2 = __shfl(v2, last, 64);
+      const int last = (lane - pos + cnt - 1) << 2;
+      const double a0 = lane_read(v0, last), a1 = lane_read(v1, last), a2 = lane_read(v2, last);
       if (valid) {
         // rec[3..8] = diag(sp) C^-1 diag(sp);  y = -that * sum E'u
         const double y0 = -(rec[3] * a0 + rec[4] * a1 + rec[6] * a2);

@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from bundle_adjustment_amd import miba, synth
 pr = synth.make_problem(40, 3000, 14000, seed=11, shuffle_obs=True)
 cams0, pts0 = synth.perturb(pr, 0.01, 0.1, seed=12)

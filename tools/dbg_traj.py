@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from bundle_adjustment_amd import miba, synth
 from oracle import oracle as O
 pr = synth.make_problem(40, 3000, 14000, seed=11, shuffle_obs=True)

@@ -1,6 +1,6 @@
 """Time the implicit-Schur product in isolation on a synthetic config (GPU).  usage: time_k3.py [config] [reps]"""
 import os, sys, json, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from bundle_adjustment_amd import miba, synth
 cfg = sys.argv[1] if len(sys.argv) > 1 else "final-13682"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
