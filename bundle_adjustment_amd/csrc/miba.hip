@@ -70,7 +70,7 @@ struct miba_handle_s {
   double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
   int32_t n_giant = 0;
-  bool use_mf = true;                             // matrix-free K3 (MIBA_MF=0 turns it off)
+  bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
   double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
   double *d_slab64 = nullptr, *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
@@ -204,9 +204,17 @@ int launch_cam_tables(miba_handle h, const double* cam, bool candidate = false) 
   return MIBA_OK;
 }
 
+// the stored Jacobian (26 doubles per slot) exists only for miba_evaluate and the MIBA_MF=0 path
+int ensure_J(miba_handle h) {
+  if (h->d_J) return MIBA_OK;
+  return dev_alloc(h, &h->d_J, (size_t)kJComp * (size_t)(h->n_slots ? h->n_slots : 1));
+}
+
 // residual + Jacobian at (cam, X); cost -> d_sum[S_COST] (all-reduced)
 int eval_jac(miba_handle h, const double* cam, const double* X, bool scaled) {
-  int rc = launch_cam_tables(h, cam);
+  int rc = ensure_J(h);
+  if (rc) return rc;
+  rc = launch_cam_tables(h, cam);
   if (rc) return rc;
   if (h->n_tiles) {
     Timed t(h, MIBA_K_EVAL_JAC);
@@ -238,10 +246,35 @@ int eval_cost(miba_handle h, const double* cam, const double* X) {
 constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 + 4) * sizeof(double);
 
 // K2 + camera reductions + camera blocks; fills Cinv, gp, Minv, Dc2, rhs and the gradient norms
+// K2-mf over all tiles of this shard (camera tables of the current state must be in d_ct / d_cm):
+// per-point blocks, raw camera slab rows, cost -> d_sum[S_COST] (all-reduced)
+int mf_init_launch(miba_handle h, double inv_r, const miba_options* o) {
+  if (h->n_tiles) {
+    Timed t(h, MIBA_K_SCHUR_INIT);
+    hipLaunchKernelGGL(k_mf_init<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
+                       h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm, h->d_X,
+                       h->d_sp, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp, h->d_dgp, h->d_ptrec,
+                       h->d_slab64, h->d_part_tile, h->d_ctl);
+    if (h->n_giant)
+      hipLaunchKernelGGL(k_mf_init<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
+                         h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm, h->d_X, h->d_sp,
+                         inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp, h->d_dgp, h->d_ptrec, h->d_slab64,
+                         h->d_part_tile, h->d_ctl);
+  }
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
+  HIPCHK(h, hipGetLastError());
+  return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
+}
+
 int schur_init(miba_handle h, double radius, const miba_options* o) {
   const double inv_r = 1.0 / radius;
   HIPCHK(h, hipMemsetAsync(&h->d_ctl->fail, 0, sizeof(int32_t), h->st));
-  if (h->n_tiles) {
+  int rc;
+  if (h->use_mf) {
+    rc = mf_init_launch(h, inv_r, o);
+    if (rc) return rc;
+  } else if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
     hipLaunchKernelGGL(k_schur_init, dim3((unsigned)h->n_tiles), dim3(kChunk), kK2Lds, h->st, h->d_tiles, h->d_grps, h->d_idx,
                        h->d_pt_rng, h->d_slab_row, h->d_J, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp,
@@ -249,9 +282,9 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   }
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab64,
-                     h->d_camacc);
+                     h->use_mf ? h->d_sc : (const double*)nullptr, h->d_camacc);
   HIPCHK(h, hipGetLastError());
-  int rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
+  rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
   if (rc) return rc;
   const int nb = nblk(h->n_cam, 64);
   hipLaunchKernelGGL(k_cam_blocks, dim3(nb), dim3(64), 0, h->st, h->n_cam, h->d_camacc, h->d_cam_active, h->d_sc, inv_r,
@@ -317,6 +350,26 @@ int make_scale(miba_handle h) {
   return MIBA_OK;
 }
 
+int unit_scale(miba_handle h);
+
+// Jacobi scale of the matrix-free path: one K2-mf pass with unit scales gives the squared column norms
+// as diag(F'F) per camera and diag(E'E) per point
+int make_scale_mf(miba_handle h, const miba_options* o) {
+  int rc = unit_scale(h);
+  if (rc) return rc;
+  rc = mf_init_launch(h, 1.0, o);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab64,
+                     (const double*)nullptr, h->d_camacc);
+  HIPCHK(h, hipGetLastError());
+  rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scale_from_acc, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, h->d_camacc, h->d_sc);
+  hipLaunchKernelGGL(k_make_scale, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_dgp, h->d_sp);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
 int unit_scale(miba_handle h) {
   hipLaunchKernelGGL(k_fill, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, 1.0, h->d_sc);
   hipLaunchKernelGGL(k_fill, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, 1.0, h->d_sp);
@@ -371,7 +424,18 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
 
 // back-substitution, candidate state, model cost change, step / candidate norms
 int backsub_and_candidate(miba_handle h) {
-  if (h->n_tiles) {
+  if (h->use_mf) {
+    if (h->n_tiles) {
+      Timed t(h, MIBA_K_BACKSUB);
+      hipLaunchKernelGGL(k_mf_backsub<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
+                         h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
+                         h->d_ptrec, h->d_px, h->d_yp, h->d_Xc, h->d_part_tile);
+      if (h->n_giant)
+        hipLaunchKernelGGL(k_mf_backsub<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
+                           h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct, h->d_cm, h->d_sc, h->d_sp, h->d_ptrec,
+                           h->d_px, h->d_yp, h->d_Xc, h->d_part_tile);
+    }
+  } else if (h->n_tiles) {
     Timed t(h, MIBA_K_BACKSUB);
     hipLaunchKernelGGL(k_backsub, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
                        h->d_pt_rng, h->d_tile_cams, h->d_J, h->d_Cinv, h->d_gp, h->d_px, h->d_sp, h->d_X, h->d_yp, h->d_Xc,
@@ -419,6 +483,20 @@ int read_scalars(miba_handle h) {
 // make d_J the scaled Jacobian of the current state (computing the Jacobi scale on first use)
 int ensure_jacobian(miba_handle h, const miba_options* o) {
   int rc;
+  if (h->use_mf) {
+    // matrix-free: nothing is stored per observation; only the camera tables and (once) the Jacobi scale
+    if (!h->jac_valid || !h->scale_valid) {
+      rc = launch_cam_tables(h, h->d_cam);
+      if (rc) return rc;
+    }
+    if (!h->scale_valid) {
+      rc = o->jacobi_scaling ? make_scale_mf(h, o) : unit_scale(h);
+      if (rc) return rc;
+      h->scale_valid = true;
+    }
+    h->jac_valid = true;
+    return MIBA_OK;
+  }
   if (!h->scale_valid) {
     if (o->jacobi_scaling) {
       rc = eval_jac(h, h->d_cam, h->d_X, false);
@@ -674,13 +752,13 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   ALLOC(h->d_cam_row_off, nc + 1); ALLOC(h->d_pt_rng, np); ALLOC(h->d_cam_active, nc); ALLOC(h->d_wl, wlv.size());
   ALLOC(h->d_oxy, 2 * ns);
   ALLOC(h->d_cam, 9 * nc); ALLOC(h->d_cam_cand, 9 * nc); ALLOC(h->d_ct, (size_t)kCamTabStride * nc); ALLOC(h->d_sc, 9 * nc);
-  ALLOC(h->d_ct_cand, (size_t)kCamTabStride * nc); ALLOC(h->d_cm, 10 * nc); ALLOC(h->d_ptrec, 10 * np);
+  ALLOC(h->d_ct_cand, (size_t)kCamTabStride * nc); ALLOC(h->d_cm, 10 * nc); ALLOC(h->d_ptrec, (size_t)kPtRec * np);
   std::vector<int32_t> giant;
   for (size_t i = 0; i < tiles.size(); ++i) if (tiles[i].giant) giant.push_back((int32_t)i);
   h->n_giant = (int32_t)giant.size();
   ALLOC(h->d_giant, giant.size());
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
-  ALLOC(h->d_J, (size_t)kJComp * ns);
+  h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
   ALLOC(h->d_slab64, (size_t)kK2W * n_rows); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
   ALLOC(h->d_camacc, (size_t)kK2W * nc); ALLOC(h->d_Minv, 81 * nc); ALLOC(h->d_Dc2, 9 * nc); ALLOC(h->d_rhs, 9 * nc);
@@ -715,7 +793,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   std::vector<int32_t>().swap(P.ocam);
   h->has_problem = true;
   {
-    const char* mf = getenv("MIBA_MF");   // matrix-free K3 is the default; MIBA_MF=0 selects the stored-Jacobian product
+    const char* mf = getenv("MIBA_MF");   // matrix-free kernels are the default; MIBA_MF=0 selects the stored-Jacobian path
     h->use_mf = !(mf && mf[0] == '0');
   }
   memset(&h->kt, 0, sizeof(h->kt));

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ til
                                                     double* __restrict__ dgp /*[npt][3] diag E'E*/,
                                                     double* __restrict__ slab /*[nrows][64]*/, Ctl* __restrict__ ctl,
                                                     const double* __restrict__ X, const double* __restrict__ sp,
-                                                    double* __restrict__ ptrec /*[npt][10]: X, sp C^-1 sp, range*/) {
+                                                    double* __restrict__ ptrec /*[npt][kPtRec]: X, sp C^-1 sp, sp C^-1 g*/) {
   extern __shared__ double lds[];
   double* s_acc = lds;                              // [kMaxCamSlots][63]  (stride 63: odd => fewer bank conflicts)
   double* s_stage = lds + kMaxCamSlots * 63;        // [256][9]
@@ -359,17 +359,18 @@ __global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ til
         for (int k = 0; k < 6; ++k) Cinv[6 * (size_t)p + k] = ci[k];
         {
           // per-point record of the matrix-free product: X, diag(sp) C^-1 diag(sp), slot range in the chunk
-          double* rp = ptrec + 10 * (size_t)p;
+          double* rp = ptrec + (size_t)kPtRec * (size_t)p;
           const double s0 = sp[3 * (size_t)p], s1 = sp[3 * (size_t)p + 1], s2 = sp[3 * (size_t)p + 2];
           rp[0] = X[3 * (size_t)p]; rp[1] = X[3 * (size_t)p + 1]; rp[2] = X[3 * (size_t)p + 2];
           rp[3] = s0 * ci[0] * s0; rp[4] = s1 * ci[1] * s0; rp[5] = s1 * ci[2] * s1;
           rp[6] = s2 * ci[3] * s0; rp[7] = s2 * ci[4] * s1; rp[8] = s2 * ci[5] * s2;
-          rp[9] = __longlong_as_double((long long)(l0 | (rg.y << 16)));
         }
         gp[3 * (size_t)p] = a[6]; gp[3 * (size_t)p + 1] = a[7]; gp[3 * (size_t)p + 2] = a[8];
         s_y[tid * 3 + 0] = ci[0] * a[6] + ci[1] * a[7] + ci[3] * a[8];
         s_y[tid * 3 + 1] = ci[1] * a[6] + ci[2] * a[7] + ci[4] * a[8];
         s_y[tid * 3 + 2] = ci[3] * a[6] + ci[4] * a[7] + ci[5] * a[8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ptrec[(size_t)kPtRec * (size_t)p + 9 + k] = sp[3 * (size_t)p + k] * s_y[tid * 3 + k];
       }
       __syncthreads();
       if (valid) {
@@ -795,13 +796,25 @@ __global__ __launch_bounds__(256) void k_cam_reduce9(int n_cam, const int32_t* _
 }
 
 // W = 64: out[c][0..63] = sum rows (lane = component)
+// sc != null: the rows hold sums of the UNSCALED Jacobian (K2-mf); entry (i,j) of F'F is scaled by
+// sc_i sc_j, F'v and F'r by sc_i.
 __global__ __launch_bounds__(256) void k_cam_reduce64(int n_cam, const int32_t* __restrict__ cam_row_off,
-                                                      const double* __restrict__ slab, double* __restrict__ out) {
+                                                      const double* __restrict__ slab, const double* __restrict__ sc,
+                                                      double* __restrict__ out) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_cam) return;
   const int lane = threadIdx.x & 63;
   double a0 = 0.0;
   for (int r = cam_row_off[c]; r < cam_row_off[c + 1]; ++r) a0 += slab[(size_t)kK2W * r + lane];
+  if (sc && lane < 63) {
+    const double* s = sc + 9 * (size_t)c;
+    if (lane >= 45) a0 *= s[(lane - 45) % 9];
+    else {
+      int i = 0, off = 0;
+      while (lane >= off + (9 - i)) { off += 9 - i; ++i; }
+      a0 *= s[i] * s[i + (lane - off)];
+    }
+  }
   out[(size_t)kK2W * c + lane] = a0;
 }
 

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
                                                    const double* __restrict__ ct, const double* __restrict__ cm,
                                                    const double* __restrict__ sc, const double* __restrict__ sp,
                                                    const double* __restrict__ X, const double* __restrict__ Cinv,
-                                                   const double* __restrict__ ptrec /*[npt][10]*/,
+                                                   const double* __restrict__ ptrec /*[npt][kPtRec]*/,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
                                                    const Ctl* __restrict__ ctl) {
   __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
       // the point's record, gathered per observation (lanes of one point read the same 72 bytes)
       double rec[9];
       if (valid) {
-        const double* rp = ptrec + 10 * (size_t)(gpt0 + pl);
+        const double* rp = ptrec + (size_t)kPtRec * (size_t)(gpt0 + pl);
 #pragma unroll
         for (int k = 0; k < 9; ++k) rec[k] = rp[k];
       } else {
@@ -248,6 +248,410 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
       }
     }
   }
+}
+
+// =============================================================================================
+// Matrix-free Schur init (K2-mf) and back-substitution (K4-mf): the LM loop never stores J.
+// =============================================================================================
+
+// camera record of K2-mf: [R 0..8 | t 9..11 | f k1 k2 12..14 | M 15..23 | small 24]
+__device__ __forceinline__ void mf_stage_cam_init(double* dst, int cam, const double* __restrict__ ct,
+                                                  const double* __restrict__ cm) {
+  const double* T = ct + (size_t)kCamTabStride * cam;
+  const double* M = cm + 10 * (size_t)cam;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) dst[k] = T[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dst[15 + k] = M[k];
+  dst[24] = M[9];
+}
+
+// Unscaled Jacobian blocks and residual of one observation (same derivative as k_eval<true>, through
+// d(R X)/dw = -N [X]x M):  F row i = [ (X x ep_i)' M | A_i | d p_i, f n p_i, f n^2 p_i ],  E = A R.
+__device__ __forceinline__ void mf_blocks(const double* cd, double x0, double x1, double x2, double ox, double oy, double* F,
+                                          double* E, double& r0, double& r1) {
+  const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
+  const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
+  const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
+  const double f = cd[12], k1 = cd[13], k2 = cd[14];
+  const double iz = 1.0 / P2;
+  const double px = -P0 * iz, py = -P1 * iz;
+  const double n = px * px + py * py;
+  const double d = 1.0 + n * (k1 + k2 * n);
+  r0 = f * d * px - ox;
+  r1 = f * d * py - oy;
+  const double gg = k1 + 2.0 * k2 * n;
+  const double m00 = f * (d + 2.0 * gg * px * px), m01 = f * (2.0 * gg * px * py), m11 = f * (d + 2.0 * gg * py * py);
+  const double q0 = P0 * iz * iz, q1 = P1 * iz * iz;
+  double A[6];
+  A[0] = -m00 * iz; A[1] = -m01 * iz; A[2] = m00 * q0 + m01 * q1;
+  A[3] = -m01 * iz; A[4] = -m11 * iz; A[5] = m01 * q0 + m11 * q1;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    E[j] = A[0] * cd[j] + A[1] * cd[3 + j] + A[2] * cd[6 + j];
+    E[3 + j] = A[3] * cd[j] + A[4] * cd[3 + j] + A[5] * cd[6 + j];
+  }
+  const bool small = cd[24] != 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double e0 = small ? A[3 * i] : E[3 * i], e1 = small ? A[3 * i + 1] : E[3 * i + 1], e2 = small ? A[3 * i + 2] : E[3 * i + 2];
+    const double g0 = x1 * e2 - x2 * e1, g1 = x2 * e0 - x0 * e2, g2 = x0 * e1 - x1 * e0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) F[9 * i + j] = g0 * cd[15 + j] + g1 * cd[18 + j] + g2 * cd[21 + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) F[9 * i + 3 + j] = A[3 * i + j];
+  }
+  F[6] = d * px;          F[15] = d * py;
+  F[7] = f * n * px;      F[16] = f * n * py;
+  F[8] = f * n * n * px;  F[17] = f * n * n * py;
+}
+
+// per-point part of the Schur init from the raw sums a = {E'E (00,10,11,20,21,22), E'r}: scaled C^-1 (ci),
+// scaled gradient (g), scaled diag(E'E) (dg), W = sp C^-1 sp and z = sp.(C^-1 g).  false: C not SPD.
+__device__ __forceinline__ bool mf_point_solve(const double* a, double s0, double s1, double s2, double inv_radius, double dmin,
+                                               double dmax, double* ci, double* g, double* dg, double* W, double* z) {
+  double c[6] = {s0 * a[0] * s0, s1 * a[1] * s0, s1 * a[2] * s1, s2 * a[3] * s0, s2 * a[4] * s1, s2 * a[5] * s2};
+  dg[0] = c[0]; dg[1] = c[2]; dg[2] = c[5];
+  c[0] += fmin(fmax(c[0], dmin), dmax) * inv_radius;
+  c[2] += fmin(fmax(c[2], dmin), dmax) * inv_radius;
+  c[5] += fmin(fmax(c[5], dmin), dmax) * inv_radius;
+  const bool ok = spd3_inverse(c, ci);
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ci[k] = 0.0;
+  }
+  g[0] = s0 * a[6]; g[1] = s1 * a[7]; g[2] = s2 * a[8];
+  W[0] = s0 * ci[0] * s0; W[1] = s1 * ci[1] * s0; W[2] = s1 * ci[2] * s1;
+  W[3] = s2 * ci[3] * s0; W[4] = s2 * ci[4] * s1; W[5] = s2 * ci[5] * s2;
+  z[0] = s0 * (ci[0] * g[0] + ci[1] * g[1] + ci[3] * g[2]);
+  z[1] = s1 * (ci[1] * g[0] + ci[2] * g[1] + ci[4] * g[2]);
+  z[2] = s2 * (ci[3] * g[0] + ci[4] * g[1] + ci[5] * g[2]);
+  return ok;
+}
+
+// camera-row contribution of one observation: upper triangle of F'F (45), F'v (9), F'r (9); ATOMIC: LDS accumulate
+template <bool ATOMIC>
+__device__ __forceinline__ void mf_cam_row(double* dst, const double* F, double v0, double v1, double r0, double r1) {
+  int o = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = i; j < 9; ++j) {
+      const double v = F[i] * F[j] + F[9 + i] * F[9 + j];
+      if (ATOMIC) atomicAdd(dst + o, v); else dst[o] = v;
+      ++o;
+    }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double v = F[k] * v0 + F[9 + k] * v1;
+    const double u = F[k] * r0 + F[9 + k] * r1;
+    if (ATOMIC) { atomicAdd(dst + 45 + k, v); atomicAdd(dst + 54 + k, u); }
+    else { dst[45 + k] = v; dst[54 + k] = u; }
+  }
+  if (!ATOMIC) dst[63] = 0.0;
+}
+
+// K2-mf: residual, cost, per-point Schur elimination and per-camera sums straight from the state.
+// Column scaling is NOT applied to F here (the raw camera sums are scaled by k_cam_reduce64); the point
+// scaling sp enters through mf_point_solve.  partial_cost[tile] = 0.5 sum r^2.
+template <bool GIANT>
+__global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                 const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                 const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
+                                                 const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
+                                                 const double* __restrict__ oxy, const double* __restrict__ ct,
+                                                 const double* __restrict__ cm, const double* __restrict__ X,
+                                                 const double* __restrict__ sp, double inv_radius, double dmin, double dmax,
+                                                 double* __restrict__ Cinv, double* __restrict__ gp, double* __restrict__ dgp,
+                                                 double* __restrict__ ptrec, double* __restrict__ slab /*[rows][64]*/,
+                                                 double* __restrict__ partial_cost, Ctl* __restrict__ ctl) {
+  __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
+  __shared__ double s_acc[GIANT ? 1 : kMaxCamSlots * 63];
+  __shared__ double s4[4];
+  const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
+  const Tile t = tiles[tile_id];
+  if (!GIANT && t.giant) return;
+  const int tid = threadIdx.x;
+  double cost = 0.0;
+  if (!GIANT) {
+    if (tid < t.ncs) mf_stage_cam_init(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm);
+    for (int i = tid; i < t.ncs * 63; i += kChunk) s_acc[i] = 0.0;
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int nwl = t.nslot / kWave;
+    for (int q = wv; q < nwl; q += 4) {
+      const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
+      const int32_t w = idx[slot];
+      const int maxrun = wl[(t.slot0 >> 6) + q].y;
+      const int gpt0 = grps[t.grp0 + (q >> 2)].pt0;
+      const bool valid = w >= 0;
+      const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
+      const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
+      const size_t p = (size_t)(gpt0 + pl);
+      double F[18], E[6], r0 = 0.0, r1 = 0.0, v[9];
+      double x0 = 0, x1 = 0, x2 = 0, s0 = 1, s1 = 1, s2 = 1;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = 0.0;
+      if (valid) {
+        x0 = X[3 * p]; x1 = X[3 * p + 1]; x2 = X[3 * p + 2];
+        s0 = sp[3 * p]; s1 = sp[3 * p + 1]; s2 = sp[3 * p + 2];
+        const size_t chunk = slot / kChunk, l = slot % kChunk;
+        const double ox = oxy[chunk * (2 * kChunk) + l], oy = oxy[chunk * (2 * kChunk) + kChunk + l];
+        mf_blocks(s_cam + kCamLds * cs, x0, x1, x2, ox, oy, F, E, r0, r1);
+        cost += r0 * r0 + r1 * r1;
+        v[0] = E[0] * E[0] + E[3] * E[3];
+        v[1] = E[1] * E[0] + E[4] * E[3];
+        v[2] = E[1] * E[1] + E[4] * E[4];
+        v[3] = E[2] * E[0] + E[5] * E[3];
+        v[4] = E[2] * E[1] + E[5] * E[4];
+        v[5] = E[2] * E[2] + E[5] * E[5];
+        v[6] = E[0] * r0 + E[3] * r1;
+        v[7] = E[1] * r0 + E[4] * r1;
+        v[8] = E[2] * r0 + E[5] * r1;
+      }
+      for (int d = 1; d < maxrun; d <<= 1) {
+        const int src = (lane - d) << 2;
+        const bool in = pos >= d;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double tk = lane_read(v[k], src);
+          v[k] += in ? tk : 0.0;
+        }
+      }
+      const int last = (lane - pos + cnt - 1) << 2;
+      double a[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a[k] = lane_read(v[k], last);
+      double ci[6], g[3], dg[3], W[6], z[3];
+      const bool ok = mf_point_solve(a, s0, s1, s2, inv_radius, dmin, dmax, ci, g, dg, W, z);
+      if (valid) {
+        if (pos == 0) {
+          if (!ok) ctl->fail = 1;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Cinv[6 * p + k] = ci[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { gp[3 * p + k] = g[k]; dgp[3 * p + k] = dg[k]; }
+          double* rp = ptrec + (size_t)kPtRec * p;
+          rp[0] = x0; rp[1] = x1; rp[2] = x2;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) rp[3 + k] = W[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) rp[9 + k] = z[k];
+        }
+        const double v0 = r0 - (E[0] * z[0] + E[1] * z[1] + E[2] * z[2]);
+        const double v1 = r1 - (E[3] * z[0] + E[4] * z[1] + E[5] * z[2]);
+        mf_cam_row<true>(s_acc + 63 * cs, F, v0, v1, r0, r1);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < t.ncs * kK2W; i += kChunk) {
+      const int s = i >> 6, k = i & 63;
+      slab[(size_t)kK2W * slab_row[t.cam0 + s] + k] = (k < 63) ? s_acc[s * 63 + k] : 0.0;
+    }
+  } else {
+    for (int gi = 0; gi < t.ngrp; ++gi) {
+      const Group G = grps[t.grp0 + gi];
+      const size_t p = (size_t)G.pt0;
+      const double x0 = X[3 * p], x1 = X[3 * p + 1], x2 = X[3 * p + 2];
+      const double s0 = sp[3 * p], s1 = sp[3 * p + 1], s2 = sp[3 * p + 2];
+      double a[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a[k] = 0.0;
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = 0.0;
+        if (idx[slot] >= 0) {
+          double cd[kCamLds], F[18], E[6], r0, r1;
+          mf_stage_cam_init(cd, ocam[slot], ct, cm);
+          mf_blocks(cd, x0, x1, x2, oxy[chunk * (2 * kChunk) + tid], oxy[chunk * (2 * kChunk) + kChunk + tid], F, E, r0, r1);
+          cost += r0 * r0 + r1 * r1;
+          v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[1] * E[0] + E[4] * E[3]; v[2] = E[1] * E[1] + E[4] * E[4];
+          v[3] = E[2] * E[0] + E[5] * E[3]; v[4] = E[2] * E[1] + E[5] * E[4]; v[5] = E[2] * E[2] + E[5] * E[5];
+          v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] += block_sum(v[k], s4);
+      }
+      double ci[6], g[3], dg[3], W[6], z[3];
+      const bool ok = mf_point_solve(a, s0, s1, s2, inv_radius, dmin, dmax, ci, g, dg, W, z);
+      if (tid == 0) {
+        if (!ok) ctl->fail = 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Cinv[6 * p + k] = ci[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gp[3 * p + k] = g[k]; dgp[3 * p + k] = dg[k]; }
+        double* rp = ptrec + (size_t)kPtRec * p;
+        rp[0] = x0; rp[1] = x1; rp[2] = x2;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rp[3 + k] = W[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rp[9 + k] = z[k];
+      }
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        if (idx[slot] < 0) continue;
+        double cd[kCamLds], F[18], E[6], r0, r1;
+        mf_stage_cam_init(cd, ocam[slot], ct, cm);
+        mf_blocks(cd, x0, x1, x2, oxy[chunk * (2 * kChunk) + tid], oxy[chunk * (2 * kChunk) + kChunk + tid], F, E, r0, r1);
+        const double v0 = r0 - (E[0] * z[0] + E[1] * z[1] + E[2] * z[2]);
+        const double v1 = r1 - (E[3] * z[0] + E[4] * z[1] + E[5] * z[2]);
+        mf_cam_row<false>(slab + (size_t)kK2W * slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)], F, v0, v1, r0, r1);
+      }
+    }
+  }
+  const double tot = block_sum(cost, s4);
+  if (tid == 0) partial_cost[tile_id] = 0.5 * tot;
+}
+
+// K4-mf: back-substitution  z_p = sp.(C^-1 (g_p - sum E_s' F_s y_c)) = zg - W sum E'u, candidate points
+// Xc = X - z, yp = z / sp, and partial[4*tile + {0,1,2}] = {sum m.(r - m/2), |X - Xc|^2, |Xc|^2}, m = u + E z.
+template <bool GIANT>
+__global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                    const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
+                                                    const int32_t* __restrict__ tile_cams, const double* __restrict__ oxy,
+                                                    const double* __restrict__ ct, const double* __restrict__ cm,
+                                                    const double* __restrict__ sc, const double* __restrict__ sp,
+                                                    const double* __restrict__ ptrec, const double* __restrict__ yc,
+                                                    double* __restrict__ yp, double* __restrict__ Xc,
+                                                    double* __restrict__ partial) {
+  __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
+  __shared__ double s4[4];
+  const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
+  const Tile t = tiles[tile_id];
+  if (!GIANT && t.giant) return;
+  const int tid = threadIdx.x;
+  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0;
+  if (!GIANT) {
+    if (tid < t.ncs) mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, yc);
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int nwl = t.nslot / kWave;
+    for (int q = wv; q < nwl; q += 4) {
+      const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
+      const int32_t w = idx[slot];
+      const int maxrun = wl[(t.slot0 >> 6) + q].y;
+      const int gpt0 = grps[t.grp0 + (q >> 2)].pt0;
+      const bool valid = w >= 0;
+      const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
+      const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
+      const size_t p = (size_t)(gpt0 + pl);
+      double rec[kPtRec];
+#pragma unroll
+      for (int k = 0; k < kPtRec; ++k) rec[k] = 0.0;
+      MfGeo geo;
+      double u0 = 0, u1 = 0, v0 = 0, v1 = 0, v2 = 0, r0 = 0, r1 = 0;
+      if (valid) {
+        const double* rp = ptrec + (size_t)kPtRec * p;
+#pragma unroll
+        for (int k = 0; k < kPtRec; ++k) rec[k] = rp[k];
+        const double* cd = s_cam + kCamLds * cs;
+        mf_geom(cd, rec[0], rec[1], rec[2], geo);
+        mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
+        v0 = geo.E[0] * u0 + geo.E[3] * u1;
+        v1 = geo.E[1] * u0 + geo.E[4] * u1;
+        v2 = geo.E[2] * u0 + geo.E[5] * u1;
+        const size_t chunk = slot / kChunk, l = slot % kChunk;
+        r0 = geo.f * geo.d * geo.px - oxy[chunk * (2 * kChunk) + l];
+        r1 = geo.f * geo.d * geo.py - oxy[chunk * (2 * kChunk) + kChunk + l];
+      }
+      for (int d = 1; d < maxrun; d <<= 1) {
+        const int src = (lane - d) << 2;
+        const double t0 = lane_read(v0, src), t1 = lane_read(v1, src), t2 = lane_read(v2, src);
+        const bool in = pos >= d;
+        v0 += in ? t0 : 0.0; v1 += in ? t1 : 0.0; v2 += in ? t2 : 0.0;
+      }
+      const int last = (lane - pos + cnt - 1) << 2;
+      const double a0 = lane_read(v0, last), a1 = lane_read(v1, last), a2 = lane_read(v2, last);
+      if (valid) {
+        const double z0 = rec[9] - (rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
+        const double z1 = rec[10] - (rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
+        const double z2 = rec[11] - (rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
+        const double m0 = u0 + geo.E[0] * z0 + geo.E[1] * z1 + geo.E[2] * z2;
+        const double m1 = u1 + geo.E[3] * z0 + geo.E[4] * z1 + geo.E[5] * z2;
+        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
+        if (pos == 0) {
+          yp[3 * p] = z0 / sp[3 * p]; yp[3 * p + 1] = z1 / sp[3 * p + 1]; yp[3 * p + 2] = z2 / sp[3 * p + 2];
+          const double c0 = rec[0] - z0, c1 = rec[1] - z1, c2 = rec[2] - z2;
+          Xc[3 * p] = c0; Xc[3 * p + 1] = c1; Xc[3 * p + 2] = c2;
+          const double e0 = rec[0] - c0, e1 = rec[1] - c1, e2 = rec[2] - c2;   // step norm exactly as Ceres: |x - x_cand|
+          dp2 += e0 * e0 + e1 * e1 + e2 * e2;
+          xp2 += c0 * c0 + c1 * c1 + c2 * c2;
+        }
+      }
+    }
+  } else {
+    for (int gi = 0; gi < t.ngrp; ++gi) {
+      const Group G = grps[t.grp0 + gi];
+      const size_t p = (size_t)G.pt0;
+      double rec[kPtRec];
+#pragma unroll
+      for (int k = 0; k < kPtRec; ++k) rec[k] = ptrec[(size_t)kPtRec * p + k];
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t slot = (size_t)(G.chunk0 + ch) * kChunk + tid;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        if (idx[slot] >= 0) {
+          double cd[kCamLds];
+          mf_stage_cam(cd, ocam[slot], ct, cm, sc, yc);
+          MfGeo geo;
+          double u0, u1;
+          mf_geom(cd, rec[0], rec[1], rec[2], geo);
+          mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
+          v0 = geo.E[0] * u0 + geo.E[3] * u1; v1 = geo.E[1] * u0 + geo.E[4] * u1; v2 = geo.E[2] * u0 + geo.E[5] * u1;
+        }
+        a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
+      }
+      const double z0 = rec[9] - (rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
+      const double z1 = rec[10] - (rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
+      const double z2 = rec[11] - (rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
+      if (tid == 0) {
+        yp[3 * p] = z0 / sp[3 * p]; yp[3 * p + 1] = z1 / sp[3 * p + 1]; yp[3 * p + 2] = z2 / sp[3 * p + 2];
+        const double c0 = rec[0] - z0, c1 = rec[1] - z1, c2 = rec[2] - z2;
+        Xc[3 * p] = c0; Xc[3 * p + 1] = c1; Xc[3 * p + 2] = c2;
+        const double e0 = rec[0] - c0, e1 = rec[1] - c1, e2 = rec[2] - c2;
+        dp2 += e0 * e0 + e1 * e1 + e2 * e2;
+        xp2 += c0 * c0 + c1 * c1 + c2 * c2;
+      }
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        if (idx[slot] < 0) continue;
+        double cd[kCamLds];
+        mf_stage_cam(cd, ocam[slot], ct, cm, sc, yc);
+        MfGeo geo;
+        double u0, u1;
+        mf_geom(cd, rec[0], rec[1], rec[2], geo);
+        mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
+        const double m0 = u0 + geo.E[0] * z0 + geo.E[1] * z1 + geo.E[2] * z2;
+        const double m1 = u1 + geo.E[3] * z0 + geo.E[4] * z1 + geo.E[5] * z2;
+        const double r0 = geo.f * geo.d * geo.px - oxy[chunk * (2 * kChunk) + tid];
+        const double r1 = geo.f * geo.d * geo.py - oxy[chunk * (2 * kChunk) + kChunk + tid];
+        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
+      }
+    }
+  }
+  const double q0 = block_sum(mcc, s4);
+  const double q1 = block_sum(dp2, s4);
+  const double q2 = block_sum(xp2, s4);
+  if (tid == 0) {
+    partial[4 * (size_t)tile_id + 0] = q0;
+    partial[4 * (size_t)tile_id + 1] = q1;
+    partial[4 * (size_t)tile_id + 2] = q2;
+    partial[4 * (size_t)tile_id + 3] = 0.0;
+  }
+}
+
+// Jacobi scale from the raw (unit-scale) camera sums: sc = 1 / (1 + sqrt(diag F'F))
+__global__ void k_scale_from_acc(int n_cam, const double* __restrict__ acc, double* __restrict__ sc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * n_cam) return;
+  const int c = i / 9, k = i % 9;
+  sc[i] = 1.0 / (1.0 + sqrt(acc[(size_t)kK2W * c + (k * 9 - (k * (k - 1)) / 2)]));
 }
 
 // Per camera: sum the raw slab rows in row order, then apply the camera-side transforms:
