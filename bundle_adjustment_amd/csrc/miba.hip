@@ -70,6 +70,7 @@ struct miba_handle_s {
   double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
   int32_t n_giant = 0;
+  int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
   double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
@@ -305,31 +306,33 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   return allreduce(h, h->d_max + S_GMAX_P, 1, ncclMax);
 }
 
-// y = S x  (x, y: 9*n_cam device vectors)
-int schur_matvec(miba_handle h, const double* x, double* y) {
+// y = S x  (x, y: 9*n_cam device vectors).  ctl: control block whose done flag turns the launch into a no-op;
+// part_xy (matrix-free, single GPU only): per-block partials of x.y from the camera reduction, red_nb entries.
+int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* part_xy) {
   if (h->use_mf) {
     if (h->n_tiles) {
       Timed t(h, MIBA_K_SCHUR_MATVEC);
       hipLaunchKernelGGL(k_mf_matvec<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
                          h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc,
-                         h->d_sp, h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, h->d_ctl);
+                         h->d_sp, h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, ctl);
       if (h->n_giant)
         hipLaunchKernelGGL(k_mf_matvec<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
                            h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
-                           h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, h->d_ctl);
+                           h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, ctl);
     }
-    hipLaunchKernelGGL(k_cam_reduce_mf, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
-                       h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->d_ctl);
+    hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
+                       h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->comm ? (double*)nullptr : part_xy,
+                       ctl);
     HIPCHK(h, hipGetLastError());
     return allreduce(h, y, 9 * (size_t)h->n_cam, ncclSum);
   }
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_MATVEC);
     hipLaunchKernelGGL(k_schur_matvec<0>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
-                       h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_J, h->d_Cinv, x, h->d_slab9, nullptr, h->d_ctl);
+                       h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_J, h->d_Cinv, x, h->d_slab9, nullptr, ctl);
   }
   hipLaunchKernelGGL(k_cam_reduce9, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
-                     h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->d_ctl);
+                     h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, ctl);
   HIPCHK(h, hipGetLastError());
   return allreduce(h, y, 9 * (size_t)h->n_cam, ncclSum);
 }
@@ -378,44 +381,52 @@ int unit_scale(miba_handle h) {
 }
 
 // ConjugateGradientsSolver::Solve on S y = rhs with x0 = 0.  Solution in d_px.
+// Per iteration: pcg_chkdir, the mat-vec (tiles + camera reduction, which also leaves the p.q partials) and
+// pcg_update; the control block is device-resident and double-buffered (see miba_kernels.hpp).
 int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
   const size_t n = 9 * (size_t)h->n_cam;
-  double* part_rho = h->d_part_pcg;
-  double* part_pq = h->d_part_pcg + 128;
-  double* part_q = h->d_part_pcg + 256;
-  hipLaunchKernelGGL(pcg_start, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_rhs, h->d_px, h->d_pr, h->d_ctl, part_rho);
-  hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_rho, h->d_ctl);
+  const int nb = h->pcg_nb;
+  double* part_nb = h->d_part_pcg;
+  double* part_q = h->d_part_pcg + kPcgMaxBlocks;
+  double* part_rho[2] = {h->d_part_pcg + 2 * kPcgMaxBlocks, h->d_part_pcg + 3 * kPcgMaxBlocks};
+  double* part_pq = h->d_part_pcg + 4 * kPcgMaxBlocks;
+  const bool fused_pq = h->use_mf && !h->comm;
+  const int n_pq = fused_pq ? h->red_nb : kPcgBlocks;
+  hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
+                     part_nb, part_rho[1]);
+  hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_nb, nb, h->d_ctl);
   HIPCHK(h, hipGetLastError());
   if (check_every < 1) check_every = 1;
-  int it = 0;
-  for (;;) {
-    ++it;
-    hipLaunchKernelGGL(pcg_precond, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_Minv, h->d_pr, h->d_pz, h->d_ctl, part_rho);
-    hipLaunchKernelGGL(pcg_dir, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pz, h->d_pp, h->d_ctl, part_rho);
-    hipLaunchKernelGGL(pcg_dir_commit, dim3(1), dim3(256), 0, h->st, h->d_ctl, part_rho);
+  for (int j = 1;; ++j) {
+    hipLaunchKernelGGL(pcg_chkdir, dim3(nb), dim3(256), 0, h->st, j, n, h->d_pz, h->d_pp, h->d_ctl, part_rho[(j - 1) & 1],
+                       part_rho[j & 1], nb, part_pq, n_pq, part_q, q_tol, min_it, max_it);
     HIPCHK(h, hipGetLastError());
-    int rc = schur_matvec(h, h->d_pp, h->d_pq);
-    if (rc) return rc;
-    hipLaunchKernelGGL(pcg_dot, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pp, h->d_pq, h->d_ctl, part_pq);
-    const int reset = (it % 10 == 0) ? 1 : 0;  // residual_reset_period
-    hipLaunchKernelGGL(pcg_update, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pp, h->d_pq, h->d_rhs, h->d_px, h->d_pr,
-                       h->d_ctl, part_pq, part_q, reset);
-    HIPCHK(h, hipGetLastError());
-    if (reset) {
-      rc = schur_matvec(h, h->d_px, h->d_pz);  // z is free here
-      if (rc) return rc;
-      hipLaunchKernelGGL(pcg_resid, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_rhs, h->d_pz, h->d_px, h->d_pr, h->d_ctl,
-                         part_pq, part_q);
-    }
-    hipLaunchKernelGGL(pcg_check, dim3(1), dim3(256), 0, h->st, h->d_ctl, part_pq, part_q, q_tol, min_it, max_it);
-    HIPCHK(h, hipGetLastError());
-    if (it % check_every == 0 || it >= max_it) {
-      HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
-      rc = sync_stream(h);
+    Ctl* cur = h->d_ctl + ((j - 1) & 1);   // C_{j-1}: state after the j-1 iterations tested so far
+    const int it = j - 1;
+    if (it >= 1 && (it % check_every == 0 || it >= max_it)) {
+      HIPCHK(h, hipMemcpyAsync(h->h_ctl, cur, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
+      int rc = sync_stream(h);
       if (rc) return rc;
       if (h->h_ctl->done) break;
       if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
     }
+    int rc = schur_matvec(h, h->d_pp, h->d_pq, cur, part_pq);
+    if (rc) return rc;
+    if (!fused_pq) hipLaunchKernelGGL(pcg_dot, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pp, h->d_pq, cur, part_pq);
+    const bool reset = (j % 10 == 0);  // residual_reset_period
+    if (!reset) {
+      hipLaunchKernelGGL(pcg_update<0>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
+                         h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
+    } else {
+      hipLaunchKernelGGL(pcg_update<1>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
+                         h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
+      HIPCHK(h, hipGetLastError());
+      rc = schur_matvec(h, h->d_px, h->d_pq, cur, nullptr);   // q = S p is dead once x is updated: reuse it for S x
+      if (rc) return rc;
+      hipLaunchKernelGGL(pcg_update<2>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
+                         h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
+    }
+    HIPCHK(h, hipGetLastError());
   }
   *n_it = h->h_ctl->n_it;
   *status = h->h_ctl->status;
@@ -685,6 +696,9 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   if (rc) return fail(h, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", rc);
   h->n_cam = p->n_cam;
   h->n_valid_global = P.n_valid;
+  h->pcg_nb = std::min(nblk(p->n_cam, kPcgCams), kPcgMaxBlocks);
+  h->red_cpb = 4 * nblk(p->n_cam, 4 * kPcgMaxBlocks);
+  h->red_nb = nblk(p->n_cam, h->red_cpb);
   h->t0 = P.shard_tile[h->cfg.rank];
   h->t1 = P.shard_tile[h->cfg.rank + 1];
   h->n_tiles = h->t1 - h->t0;
@@ -766,9 +780,9 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   ALLOC(h->d_probe, 9 * nc);
   ALLOC(h->d_part_tile, 4 * nt + 4);
   ALLOC(h->d_part_small, 2 * (size_t)nblk(nc, 64) + 2 * 240 + 512);
-  ALLOC(h->d_part_pcg, 384);
+  ALLOC(h->d_part_pcg, 5 * (size_t)kPcgMaxBlocks);
   ALLOC(h->d_sum, S_COUNT); ALLOC(h->d_max, S_COUNT);
-  ALLOC(h->d_ctl, 1);
+  ALLOC(h->d_ctl, 2);
   UP(h->d_tiles, tiles.data(), nt);
   UP(h->d_grps, grps.data(), grps.size());
   UP(h->d_idx, P.idx.data() + h->slot_base, ns);
@@ -785,8 +799,8 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
 #undef UP
   HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
   HIPCHK(h, hipMemsetAsync(h->d_max, 0, S_COUNT * sizeof(double), h->st));
-  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(Ctl), h->st));
-  HIPCHK(h, hipMemsetAsync(h->d_part_pcg, 0, 384 * sizeof(double), h->st));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(Ctl), h->st));
+  HIPCHK(h, hipMemsetAsync(h->d_part_pcg, 0, 5 * (size_t)kPcgMaxBlocks * sizeof(double), h->st));
   HIPCHK(h, hipStreamSynchronize(h->st));
   // the big host-side index arrays are not needed any more, except slot_orig / pt_orig (evaluate, get_state)
   std::vector<int32_t>().swap(P.idx);
@@ -966,7 +980,7 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
   if (probe && s_probe) {
     HIPCHK(h, hipMemcpy(h->d_probe, probe, n * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemsetAsync(&h->d_ctl->done, 0, sizeof(int32_t), h->st));
-    rc = schur_matvec(h, h->d_probe, h->d_pq);
+    rc = schur_matvec(h, h->d_probe, h->d_pq, h->d_ctl, nullptr);
     if (rc) return rc;
     rc = sync_stream(h);
     if (rc) return rc;
@@ -982,7 +996,7 @@ int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* a
   const size_t n = 9 * (size_t)h->n_cam;
   HIPCHK(h, hipMemcpy(h->d_probe, probe, n * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemsetAsync(&h->d_ctl->done, 0, sizeof(int32_t), h->st));
-  int rc = schur_matvec(h, h->d_probe, h->d_pq);  // warm-up
+  int rc = schur_matvec(h, h->d_probe, h->d_pq, h->d_ctl, nullptr);  // warm-up
   if (rc) return rc;
   rc = sync_stream(h);
   if (rc) return rc;
@@ -991,7 +1005,7 @@ int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* a
   HIPCHK(h, hipEventCreate(&b));
   HIPCHK(h, hipEventRecord(a, h->st));
   for (int i = 0; i < reps; ++i) {
-    rc = schur_matvec(h, h->d_probe, h->d_pq);
+    rc = schur_matvec(h, h->d_probe, h->d_pq, h->d_ctl, nullptr);
     if (rc) return rc;
   }
   HIPCHK(h, hipEventRecord(b, h->st));

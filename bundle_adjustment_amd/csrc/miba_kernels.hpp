@@ -968,101 +968,142 @@ __global__ __launch_bounds__(256) void k_sumsq(size_t n, const double* __restric
 // blocks, grid-stride; dot products leave one partial per block which the consumer kernels
 // sum in block order (deterministic, and identical on every rank).
 // ---------------------------------------------------------------------------------------------
-constexpr int kPcgBlocks = 120;
+constexpr int kPcgBlocks = 120;     // blocks of pcg_dot
+constexpr int kPcgCams = 28;        // cameras per block round of the fused kernels (252 of 256 threads)
+constexpr int kPcgMaxBlocks = 4096; // cap on the number of partials a consumer sums
 
-__device__ __forceinline__ double sum_partials(const double* __restrict__ part, double* s4) {
-  const double v = (threadIdx.x < kPcgBlocks) ? part[threadIdx.x] : 0.0;
+// sum of n per-block partials, in a fixed order; every thread gets the result
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* s4) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += kChunk) v += part[i];
   return block_sum(v, s4);
 }
 
-// start: x = 0, r = b, ctl reset; partial norm_b2
-__global__ __launch_bounds__(256) void pcg_start(size_t n, const double* __restrict__ b, double* __restrict__ x,
-                                                 double* __restrict__ r, Ctl* __restrict__ ctl, double* __restrict__ part) {
+__device__ __forceinline__ bool pcg_bad(double v) { return v == 0.0 || isinf(v) || isnan(v); }
+
+// The control block is double-buffered: C_k (state after k completed iterations) lives in ctl[k & 1], so a
+// kernel that produces C_k never writes the buffer its sibling blocks are still reading (C_{k-1}).
+//
+// One PCG iteration j (1-based) is   pcg_chkdir(j) -> mat-vec (+ pq partials) -> pcg_update(j):
+//   pcg_chkdir(j): end-of-iteration test of j-1 (C_{j-2} -> C_{j-1}), then rho_j, beta, p = z + beta p
+//   pcg_update(j): alpha = rho_j / pq; x += alpha p; r -= alpha q; Q partials; z = M^-1 r; rho_{j+1} partials
+// Every block recomputes the scalars from the same partial arrays in the same order, so all blocks (and all
+// ranks) take identical decisions.  part_rho is double-buffered by parity of the iteration that consumes it.
+
+// x = 0, r = b, z = M^-1 b; partials |b|^2 and rho_1; C_0
+__global__ __launch_bounds__(256) void pcg_start(int n_cam, const double* __restrict__ b, const double* __restrict__ Minv,
+                                                 double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                                                 Ctl* __restrict__ ctl /*[2]*/, double* __restrict__ part_nb,
+                                                 double* __restrict__ part_rho1) {
+  __shared__ double s_r[kPcgCams * 9];
   __shared__ double s4[4];
-  double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const double v = b[i];
-    x[i] = 0.0;
-    r[i] = v;
-    acc += v * v;
-  }
-  const double s = block_sum(acc, s4);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ctl->rho = 1.0; ctl->rho_prev = 1.0; ctl->Q0 = 0.0; ctl->Q1 = 0.0; ctl->zeta = 0.0;
-    ctl->pq = 0.0; ctl->alpha = 0.0; ctl->beta = 0.0;
-    ctl->done = 0; ctl->status = 1; ctl->n_it = 0;
-  }
-}
-// finish start: norm_b == 0 => done (success)
-__global__ void pcg_start2(const double* __restrict__ part, Ctl* __restrict__ ctl) {
-  __shared__ double s4[4];
-  const double nb2 = sum_partials(part, s4);
-  if (threadIdx.x == 0) {
-    ctl->norm_b2 = nb2;
-    if (nb2 == 0.0) { ctl->done = 1; ctl->status = 0; }
-  }
-}
-// z = M^-1 r (9x9 blocks); partial rho = r.z.  One thread per vector entry.
-__global__ __launch_bounds__(256) void pcg_precond(size_t n, const double* __restrict__ Minv, const double* __restrict__ r,
-                                                   double* __restrict__ z, const Ctl* __restrict__ ctl, double* __restrict__ part) {
-  __shared__ double s4[4];
-  if (ctl->done) return;
-  double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t c = i / 9;
-    const double* m = Minv + 9 * i;  // row (i%9) of block c = Minv[c*81 + (i%9)*9]
-    const double* rc = r + 9 * c;
-    double s = 0.0;
+  const int tid = threadIdx.x;
+  const int cl = tid / 9, k = tid % 9;
+  double a_nb = 0.0, a_rho = 0.0;
+  for (int c0 = blockIdx.x * kPcgCams; c0 < n_cam; c0 += gridDim.x * kPcgCams) {
+    const int c = c0 + cl;
+    const bool act = tid < kPcgCams * 9 && c < n_cam;
+    const size_t i = 9 * (size_t)c + k;
+    double v = 0.0;
+    if (act) { v = b[i]; x[i] = 0.0; r[i] = v; s_r[tid] = v; a_nb += v * v; }
+    __syncthreads();
+    if (act) {
+      const double* m = Minv + 9 * i;   // row k of the camera's 9x9 block
+      double zz = 0.0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) s += m[j] * rc[j];
-    z[i] = s;
-    acc += r[i] * s;
-  }
-  const double s = block_sum(acc, s4);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
-}
-// rho, beta; p = z + beta p
-__global__ __launch_bounds__(256) void pcg_dir(size_t n, const double* __restrict__ z, double* __restrict__ p, Ctl* __restrict__ ctl,
-                                               const double* __restrict__ part) {
-  __shared__ double s4[4];
-  if (ctl->done) return;
-  const double rho = sum_partials(part, s4);
-  const double last_rho = ctl->rho;     // written by the previous iteration's pcg_dir
-  const int it = ctl->n_it + 1;
-  bool bad = (rho == 0.0) || isinf(rho) || isnan(rho);
-  double beta = 0.0;
-  if (!bad && it > 1) {
-    beta = rho / last_rho;
-    bad = (beta == 0.0) || isinf(beta) || isnan(beta);
-  }
-  __syncthreads();  // every thread has read ctl before block 0 updates it
-  if (!bad) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-      p[i] = (it == 1) ? z[i] : z[i] + beta * p[i];
-  }
-  // ctl is only written by the LAST block to finish reading it: use a separate tail kernel instead
-}
-// tail of pcg_dir: commit rho / failure (single thread; runs after every block of pcg_dir read ctl)
-__global__ void pcg_dir_commit(Ctl* __restrict__ ctl, const double* __restrict__ part) {
-  __shared__ double s4[4];
-  if (ctl->done) return;
-  const double rho = sum_partials(part, s4);
-  if (threadIdx.x == 0) {
-    const int it = ctl->n_it + 1;
-    bool bad = (rho == 0.0) || isinf(rho) || isnan(rho);
-    double beta = 0.0;
-    if (!bad && it > 1) {
-      beta = rho / ctl->rho;
-      bad = (beta == 0.0) || isinf(beta) || isnan(beta);
+      for (int j = 0; j < 9; ++j) zz += m[j] * s_r[9 * cl + j];
+      z[i] = zz;
+      a_rho += v * zz;
     }
-    ctl->rho_prev = ctl->rho;
-    ctl->rho = rho;
-    ctl->beta = beta;
-    if (bad) { ctl->done = 1; ctl->status = 2; ctl->n_it = it; }
+    __syncthreads();
+  }
+  const double s_nb = block_sum(a_nb, s4);
+  const double s_rho = block_sum(a_rho, s4);
+  if (tid == 0) {
+    part_nb[blockIdx.x] = s_nb;
+    part_rho1[blockIdx.x] = s_rho;
+    if (blockIdx.x == 0) {
+      Ctl c;
+      c.rho = 1.0; c.rho_prev = 1.0; c.pq = 0.0; c.alpha = 0.0; c.beta = 0.0; c.Q0 = 0.0; c.Q1 = 0.0; c.zeta = 0.0;
+      c.norm_b2 = 0.0; c.done = 0; c.status = 1; c.n_it = 0; c.fail = ctl[0].fail;
+      ctl[0] = c;
+      ctl[1] = c;
+    }
   }
 }
-// partial p.q
+// finish start: norm_b == 0 => done (success, x = 0)
+__global__ void pcg_start2(const double* __restrict__ part_nb, int nb, Ctl* __restrict__ ctl) {
+  __shared__ double s4[4];
+  const double nb2 = sum_partials(part_nb, nb, s4);
+  if (threadIdx.x == 0) {
+    ctl[0].norm_b2 = nb2; ctl[1].norm_b2 = nb2;
+    if (nb2 == 0.0) { ctl[0].done = 1; ctl[0].status = 0; ctl[1].done = 1; ctl[1].status = 0; }
+  }
+}
+
+__global__ __launch_bounds__(256) void pcg_chkdir(int j, size_t n, const double* __restrict__ z, double* __restrict__ p,
+                                                  Ctl* __restrict__ ctl, const double* __restrict__ part_rho_prev,
+                                                  const double* __restrict__ part_rho_cur, int nb,
+                                                  const double* __restrict__ part_pq, int n_pq,
+                                                  const double* __restrict__ part_q, double q_tol, int min_it, int max_it) {
+  __shared__ double s4[4];
+  const Ctl* in = (j >= 2) ? &ctl[j & 1] : &ctl[0];   // C_{j-2} (C_0 for j == 1)
+  Ctl* out = &ctl[(j - 1) & 1];                       // C_{j-1}
+  Ctl c = *in;
+  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+  if (c.done) {
+    if (writer && j >= 2) *out = c;   // keep the final state in both buffers
+    return;
+  }
+  double last_rho = c.rho;
+  if (j >= 2) {
+    const int it = j - 1;
+    const double rho_it = sum_partials(part_rho_prev, nb, s4);
+    const double pq = sum_partials(part_pq, n_pq, s4);
+    c.n_it = it;
+    c.pq = pq;
+    if (pq <= 0.0 || isinf(pq) || isnan(pq)) { c.done = 1; c.status = 1; }
+    else {
+      const double alpha = rho_it / pq;
+      c.alpha = alpha;
+      if (isinf(alpha)) { c.done = 1; c.status = 2; }
+      else {
+        const double qs = sum_partials(part_q, nb, s4);
+        const double Q1 = -qs;
+        const double zeta = it * (Q1 - c.Q0) / Q1;
+        c.Q1 = Q1;
+        c.zeta = zeta;
+        if (zeta < q_tol && it >= min_it) { c.done = 1; c.status = 0; }
+        else {
+          c.Q0 = Q1;
+          if (it >= max_it) { c.done = 1; c.status = 1; }
+        }
+      }
+    }
+    if (c.done) {
+      if (writer) *out = c;
+      return;
+    }
+    last_rho = rho_it;
+  }
+  const double rho = sum_partials(part_rho_cur, nb, s4);
+  bool bad = pcg_bad(rho);
+  double beta = 0.0;
+  if (!bad && j > 1) {
+    beta = rho / last_rho;
+    bad = pcg_bad(beta);
+  }
+  c.rho_prev = last_rho;
+  c.rho = rho;
+  c.beta = beta;
+  if (bad) { c.done = 1; c.status = 2; c.n_it = j; }
+  if (writer && (j >= 2 || bad)) *out = c;
+  if (bad) return;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (j == 1) ? z[i] : z[i] + beta * p[i];
+}
+
+// partial a.b (used when the mat-vec reduction cannot produce p.q itself: stored-J path, multi-GPU)
 __global__ __launch_bounds__(256) void pcg_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b,
                                                const Ctl* __restrict__ ctl, double* __restrict__ part) {
   __shared__ double s4[4];
@@ -1072,72 +1113,61 @@ __global__ __launch_bounds__(256) void pcg_dot(size_t n, const double* __restric
   const double s = block_sum(acc, s4);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-// alpha = rho / pq ; x += alpha p ; (reset == 0) r -= alpha q ; partial Q = x.(b + r)
-// reset == 1: only x is updated here (r is rebuilt by pcg_resid after an extra mat-vec).
-__global__ __launch_bounds__(256) void pcg_update(size_t n, const double* __restrict__ p, const double* __restrict__ q,
-                                                  const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
-                                                  const Ctl* __restrict__ ctl, const double* __restrict__ part_pq,
-                                                  double* __restrict__ part_q, int reset) {
+
+// MODE 0: x += alpha p, r -= alpha q, Q partials, z = M^-1 r, next rho partials
+// MODE 1: x += alpha p only (residual-reset iteration; r is rebuilt by MODE 2 after an extra mat-vec)
+// MODE 2: r = b - q (q = S x), Q partials, z = M^-1 r, next rho partials
+template <int MODE>
+__global__ __launch_bounds__(256) void pcg_update(int n_cam, const double* __restrict__ p, const double* __restrict__ q,
+                                                  const double* __restrict__ b, const double* __restrict__ Minv,
+                                                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                                                  const Ctl* __restrict__ ctl_cur, const double* __restrict__ part_rho_cur, int nb,
+                                                  const double* __restrict__ part_pq, int n_pq, double* __restrict__ part_q,
+                                                  double* __restrict__ part_rho_next) {
+  __shared__ double s_r[kPcgCams * 9];
   __shared__ double s4[4];
-  if (ctl->done) return;
-  const double pq = sum_partials(part_pq, s4);
-  if (pq <= 0.0 || isinf(pq) || isnan(pq)) return;  // committed by pcg_update_commit
-  const double alpha = ctl->rho / pq;
+  if (ctl_cur->done) return;
+  const double rho = sum_partials(part_rho_cur, nb, s4);
+  const double pq = sum_partials(part_pq, n_pq, s4);
+  if (pq <= 0.0 || isinf(pq) || isnan(pq)) return;   // pcg_chkdir of the next iteration reports it
+  const double alpha = rho / pq;
   if (isinf(alpha)) return;
-  double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const double xv = x[i] + alpha * p[i];
-    x[i] = xv;
-    if (!reset) {
-      const double rv = r[i] - alpha * q[i];
-      r[i] = rv;
-      acc += xv * (b[i] + rv);
+  const int tid = threadIdx.x;
+  const int cl = tid / 9, k = tid % 9;
+  double a_q = 0.0, a_rho = 0.0;
+  for (int c0 = blockIdx.x * kPcgCams; c0 < n_cam; c0 += gridDim.x * kPcgCams) {
+    const int c = c0 + cl;
+    const bool act = tid < kPcgCams * 9 && c < n_cam;
+    const size_t i = 9 * (size_t)c + k;
+    double rv = 0.0;
+    if (act) {
+      double xv;
+      if (MODE == 2) xv = x[i];
+      else { xv = x[i] + alpha * p[i]; x[i] = xv; }
+      if (MODE != 1) {
+        rv = (MODE == 0) ? r[i] - alpha * q[i] : b[i] - q[i];
+        r[i] = rv;
+        a_q += xv * (b[i] + rv);
+        s_r[tid] = rv;
+      }
+    }
+    if (MODE != 1) {
+      __syncthreads();
+      if (act) {
+        const double* m = Minv + 9 * i;
+        double zz = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 9; ++jj) zz += m[jj] * s_r[9 * cl + jj];
+        z[i] = zz;
+        a_rho += rv * zz;
+      }
+      __syncthreads();
     }
   }
-  if (!reset) {
-    const double s = block_sum(acc, s4);
-    if (threadIdx.x == 0) part_q[blockIdx.x] = s;
-  }
-}
-// r = b - Sx ; partial Q
-__global__ __launch_bounds__(256) void pcg_resid(size_t n, const double* __restrict__ b, const double* __restrict__ Sx,
-                                                 const double* __restrict__ x, double* __restrict__ r, const Ctl* __restrict__ ctl,
-                                                 const double* __restrict__ part_pq, double* __restrict__ part_q) {
-  __shared__ double s4[4];
-  if (ctl->done) return;
-  const double pq = sum_partials(part_pq, s4);
-  if (pq <= 0.0 || isinf(pq) || isnan(pq) || isinf(ctl->rho / pq)) return;
-  double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const double rv = b[i] - Sx[i];
-    r[i] = rv;
-    acc += x[i] * (b[i] + rv);
-  }
-  const double s = block_sum(acc, s4);
-  if (threadIdx.x == 0) part_q[blockIdx.x] = s;
-}
-// end of iteration: pq / alpha checks, Q-tolerance test, iteration counter (single block)
-__global__ void pcg_check(Ctl* __restrict__ ctl, const double* __restrict__ part_pq, const double* __restrict__ part_q,
-                          double q_tol, int min_it, int max_it) {
-  __shared__ double s4[4];
-  if (ctl->done) return;
-  const double pq = sum_partials(part_pq, s4);
-  const double qs = sum_partials(part_q, s4);
-  if (threadIdx.x == 0) {
-    const int it = ctl->n_it + 1;
-    ctl->n_it = it;
-    ctl->pq = pq;
-    if (pq <= 0.0 || isinf(pq) || isnan(pq)) { ctl->done = 1; ctl->status = 1; return; }
-    const double alpha = ctl->rho / pq;
-    ctl->alpha = alpha;
-    if (isinf(alpha)) { ctl->done = 1; ctl->status = 2; return; }
-    const double Q1 = -qs;
-    const double zeta = it * (Q1 - ctl->Q0) / Q1;
-    ctl->Q1 = Q1;
-    ctl->zeta = zeta;
-    if (zeta < q_tol && it >= min_it) { ctl->done = 1; ctl->status = 0; return; }
-    ctl->Q0 = Q1;
-    if (it >= max_it) { ctl->done = 1; ctl->status = 1; }
+  if (MODE != 1) {
+    const double sq = block_sum(a_q, s4);
+    const double sr = block_sum(a_rho, s4);
+    if (tid == 0) { part_q[blockIdx.x] = sq; part_rho_next[blockIdx.x] = sr; }
   }
 }
 

@@ -656,41 +656,52 @@ __global__ void k_scale_from_acc(int n_cam, const double* __restrict__ acc, doub
 
 // Per camera: sum the raw slab rows in row order, then apply the camera-side transforms:
 //   out = diag_w * Dc2 .* x + sc .* [ M' c ; N a ; i_f ; f i_k1 ; f i_k2 ]
-__global__ __launch_bounds__(256) void k_cam_reduce_mf(int n_cam, const int32_t* __restrict__ cam_row_off,
+__global__ __launch_bounds__(256) void k_cam_reduce_mf(int n_cam, int cams_per_block, const int32_t* __restrict__ cam_row_off,
                                                        const double* __restrict__ slab, const double* __restrict__ ct,
                                                        const double* __restrict__ cm, const double* __restrict__ sc,
                                                        const double* __restrict__ d2, const double* __restrict__ x,
-                                                       double diag_w, double* __restrict__ out, const Ctl* __restrict__ ctl) {
+                                                       double diag_w, double* __restrict__ out,
+                                                       double* __restrict__ part_xy /*per block x.out, or null*/,
+                                                       const Ctl* __restrict__ ctl) {
+  __shared__ double s4[4];
   if (ctl->done) return;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= n_cam) return;
-  const int lane = threadIdx.x & 63;
-  const int r0 = cam_row_off[c], r1 = cam_row_off[c + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c_end = min(n_cam, (int)(blockIdx.x + 1) * cams_per_block);
   const int sub = lane / 9, k = lane % 9;
-  double acc = 0.0;
-  if (lane < 63)
-    for (int r = r0 + sub; r < r1; r += 7) acc += slab[9 * (size_t)r + k];
-  double tot = acc;
+  double xy = 0.0;
+  for (int c = blockIdx.x * cams_per_block + wv; c < c_end; c += 4) {
+    const int r0 = cam_row_off[c], r1 = cam_row_off[c + 1];
+    double acc = 0.0;
+    if (lane < 63)
+      for (int r = r0 + sub; r < r1; r += 7) acc += slab[9 * (size_t)r + k];
+    double tot = acc;
 #pragma unroll
-  for (int s = 1; s < 7; ++s) tot += __shfl(acc, k + 9 * s, 64);
-  // broadcast the 9 totals (held by lanes 0..8) to every lane
-  double v[9];
+    for (int s = 1; s < 7; ++s) tot += __shfl(acc, k + 9 * s, 64);
+    // broadcast the 9 totals (held by lanes 0..8) to every lane
+    double v[9];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) v[j] = __shfl(tot, j, 64);
-  if (lane < 9) {
-    const double* T = ct + (size_t)kCamTabStride * c;
-    const double* M = cm + 10 * (size_t)c;
-    const bool small = M[9] != 0.0;
-    double r;
-    if (lane < 3) r = M[lane] * v[0] + M[3 + lane] * v[1] + M[6 + lane] * v[2];                       // (M' c)_lane
-    else if (lane < 6) {
-      const int i = lane - 3;
-      r = small ? v[3 + i] : (T[3 * i] * v[3] + T[3 * i + 1] * v[4] + T[3 * i + 2] * v[5]);           // (N a)_i
-    } else if (lane == 6) r = v[6];
-    else r = T[12] * v[lane];
-    r *= sc[9 * (size_t)c + lane];
-    if (d2) r += diag_w * d2[9 * (size_t)c + lane] * x[9 * (size_t)c + lane];
-    out[9 * (size_t)c + lane] = r;
+    for (int j = 0; j < 9; ++j) v[j] = __shfl(tot, j, 64);
+    if (lane < 9) {
+      const double* T = ct + (size_t)kCamTabStride * c;
+      const double* M = cm + 10 * (size_t)c;
+      const bool small = M[9] != 0.0;
+      double r;
+      if (lane < 3) r = M[lane] * v[0] + M[3 + lane] * v[1] + M[6 + lane] * v[2];                       // (M' c)_lane
+      else if (lane < 6) {
+        const int i = lane - 3;
+        r = small ? v[3 + i] : (T[3 * i] * v[3] + T[3 * i + 1] * v[4] + T[3 * i + 2] * v[5]);           // (N a)_i
+      } else if (lane == 6) r = v[6];
+      else r = T[12] * v[lane];
+      r *= sc[9 * (size_t)c + lane];
+      const double xv = x[9 * (size_t)c + lane];
+      if (d2) r += diag_w * d2[9 * (size_t)c + lane] * xv;
+      out[9 * (size_t)c + lane] = r;
+      xy += xv * r;
+    }
+  }
+  if (part_xy) {
+    const double s = block_sum(xy, s4);
+    if (threadIdx.x == 0) part_xy[blockIdx.x] = s;
   }
 }
 
