@@ -741,9 +741,15 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     h->n_obs_local++;
   }
   std::vector<int2> wlv((size_t)(h->n_slots / kWave) + 1);
-  for (int64_t q = 0; q < h->n_slots / kWave; ++q) {
-    wlv[q].x = P.wl_pt0[h->slot_base / kWave + q] - h->pt_base;
-    wlv[q].y = P.wl_npt[h->slot_base / kWave + q];
+  {
+    // per wavelet: {first (local) point of the enclosing 256-slot chunk, longest point run in the wavelet}
+    std::vector<int32_t> chunk_pt0((size_t)(h->n_slots / kChunk) + 1, 0);
+    for (const auto& g : grps)
+      for (int32_t ch = g.chunk0; ch < g.chunk0 + g.nchunk; ++ch) chunk_pt0[ch] = g.pt0;
+    for (int64_t q = 0; q < h->n_slots / kWave; ++q) {
+      wlv[q].x = chunk_pt0[(size_t)(q / 4)];
+      wlv[q].y = P.wl_npt[h->slot_base / kWave + q];
+    }
   }
   std::vector<int2> pt_rng(h->n_pt ? h->n_pt : 1);
   for (int32_t q = 0; q < h->n_pt; ++q) {

@@ -50,13 +50,25 @@ struct MfGeo {
   double px, py, n, d, f;
 };
 
-// cd: camera slot data (LDS or registers), X: point
+// 1/x to within an ulp or two: v_rcp_f64 and two Newton steps (the correctly rounded division costs twice as
+// much and the operator only has to be consistent to rounding error)
+__device__ __forceinline__ double mf_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
+// cd: camera slot data (LDS or registers), X: point.  SMALL = false: no camera of the tile is in the
+// small-angle branch, Ep is E.
+template <bool SMALL = true>
 __device__ __forceinline__ void mf_geom(const double* cd, double x0, double x1, double x2, MfGeo& g) {
   const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
   const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
   const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
   const double f = cd[12], k1 = cd[13], k2 = cd[14];
-  const double iz = 1.0 / P2;
+  const double iz = mf_rcp(P2);
   const double px = -P0 * iz, py = -P1 * iz;
   const double n = px * px + py * py;
   const double d = 1.0 + n * (k1 + k2 * n);
@@ -71,9 +83,14 @@ __device__ __forceinline__ void mf_geom(const double* cd, double x0, double x1, 
     g.E[j] = A[0] * cd[j] + A[1] * cd[3 + j] + A[2] * cd[6 + j];
     g.E[3 + j] = A[3] * cd[j] + A[4] * cd[3 + j] + A[5] * cd[6 + j];
   }
-  const bool small = cd[24] != 0.0;
+  if (SMALL) {
+    const bool small = cd[24] != 0.0;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) g.Ep[j] = small ? A[j] : g.E[j];
+    for (int j = 0; j < 6; ++j) g.Ep[j] = small ? A[j] : g.E[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) g.Ep[j] = g.E[j];
+  }
   g.px = px; g.py = py; g.n = n; g.d = d; g.f = f;
 }
 
@@ -117,6 +134,87 @@ __device__ __forceinline__ double lane_read(double v, int lane_byte_addr) {
   return __hiloint2double(hi, lo);
 }
 
+// gather of the first 9 doubles of a point record (lanes of one point read the same 72 bytes)
+__device__ __forceinline__ void mf_load_rec9(double* rec, const double* __restrict__ ptrec, int32_t w, int chunk_pt0) {
+  const int pl = (w >= 0) ? (w & 0xFF) : 0;   // pad lanes read the chunk's first point: no branch, finite data
+  const double* rp = ptrec + (size_t)kPtRec * (size_t)(chunk_pt0 + pl);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rec[k] = rp[k];
+}
+
+// Wavelet loop of one wave over its tile (wavelets wv, wv+4, ...), software-pipelined: the index word of
+// wavelet i+2 and the point records of wavelet i+1 are in flight while wavelet i is computed.
+template <bool SMALL>
+__device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __restrict__ idx, const int2* __restrict__ wl,
+                                               const double* __restrict__ ptrec, const double* s_cam, double* s_acc) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nwl = t.nslot / kWave;
+  const int acc_stride = t.ncs * 9;
+  const int32_t* idxp = idx + (size_t)t.slot0 + lane;
+  const int2* wlp = wl + (t.slot0 >> 6);   // per wavelet: {first point of the enclosing chunk, longest point run}
+  int q = wv;
+  if (q >= nwl) return;
+  // the prefetches are unconditional (indices clamped to the wave's last wavelet): a load that is skipped on
+  // some path would force every wait to drain the whole queue
+  const int q_last = wv + 4 * ((nwl - 1 - wv) >> 2);
+  int32_t w_cur = idxp[(size_t)q * kWave];
+  int2 m_cur = wlp[q];
+  const int q1 = min(q + 4, q_last);
+  int32_t w_nxt = idxp[(size_t)q1 * kWave];
+  int2 m_nxt = wlp[q1];
+  double rec[9];
+  mf_load_rec9(rec, ptrec, w_cur, m_cur.x);
+  for (; q < nwl; q += 4) {
+    double rec_nxt[9];
+    mf_load_rec9(rec_nxt, ptrec, w_nxt, m_nxt.x);
+    const int q2 = min(q + 8, q_last);
+    const int32_t w_n2 = idxp[(size_t)q2 * kWave];
+    const int2 m_n2 = wlp[q2];
+    const int32_t w = w_cur;
+    const int maxrun = m_cur.y;
+    const bool valid = w >= 0;
+    const int cs = valid ? ((w >> 8) & 0xFF) : 0, pl = w & 0xFF;
+    const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
+    MfGeo geo;
+    double u0, u1;
+    int cam_off = kCamLds * cs;
+    asm volatile("" : "+v"(cam_off));   // one LDS base address; the 25 reads use immediate offsets
+    const double* cd = s_cam + cam_off;
+    mf_geom<SMALL>(cd, rec[0], rec[1], rec[2], geo);
+    mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
+    double v0 = valid ? geo.E[0] * u0 + geo.E[3] * u1 : 0.0;
+    double v1 = valid ? geo.E[1] * u0 + geo.E[4] * u1 : 0.0;
+    double v2 = valid ? geo.E[2] * u0 + geo.E[5] * u1 : 0.0;
+    // segmented inclusive scan over the lanes of each point (a point's lanes are contiguous)
+    for (int d = 1; d < maxrun; d <<= 1) {
+      const int src = (lane - d) << 2;   // byte address of the source lane (wraps harmlessly: masked by pos >= d)
+      const double t0 = lane_read(v0, src), t1 = lane_read(v1, src), t2 = lane_read(v2, src);
+      const double in = (pos >= d) ? 1.0 : 0.0;
+      v0 = fma(t0, in, v0); v1 = fma(t1, in, v1); v2 = fma(t2, in, v2);
+    }
+    // total of the run sits in its last lane
+    const int last = (lane - pos + cnt - 1) << 2;
+    const double a0 = lane_read(v0, last), a1 = lane_read(v1, last), a2 = lane_read(v2, last);
+    if (valid) {
+      // rec[3..8] = diag(sp) C^-1 diag(sp);  y = -that * sum E'u
+      const double y0 = -(rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
+      const double y1 = -(rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
+      const double y2 = -(rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
+      const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
+      const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
+      double o[9];
+      mf_transpose(geo, rec[0], rec[1], rec[2], w0, w1, o);
+      // consecutive points go to different accumulator copies: lanes of one ds_add rarely share an address
+      double* dst = s_acc + (pl & (kAccCopies - 1)) * acc_stride + 9 * cs;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) atomicAdd(dst + k, o[k]);
+    }
+    w_cur = w_nxt; m_cur = m_nxt; w_nxt = w_n2; m_nxt = m_n2;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rec[k] = rec_nxt[k];
+  }
+}
+
 template <bool GIANT>
 __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
@@ -136,66 +234,17 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
   if (!GIANT && t.giant) return;
   const int tid = threadIdx.x;
   if (!GIANT) {
-    if (tid < t.ncs) mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, x);
-    for (int i = tid; i < kAccCopies * t.ncs * 9; i += kChunk) s_acc[i] = 0.0;
-    __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
-    const int nwl = t.nslot / kWave;
-    const int acc_stride = t.ncs * 9;
-    for (int q = wv; q < nwl; q += 4) {
-      const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
-      const int32_t w = idx[slot];
-      const int maxrun = wl[(t.slot0 >> 6) + q].y;    // longest point run in this wavelet (wave-uniform)
-      const int gpt0 = grps[t.grp0 + (q >> 2)].pt0;   // first point of the enclosing 256-slot chunk
-      const bool valid = w >= 0;
-      const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
-      const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
-      // the point's record, gathered per observation (lanes of one point read the same 72 bytes)
-      double rec[9];
-      if (valid) {
-        const double* rp = ptrec + (size_t)kPtRec * (size_t)(gpt0 + pl);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rec[k] = rp[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rec[k] = 0.0;
-      }
-      MfGeo geo;
-      double u0 = 0, u1 = 0, v0 = 0, v1 = 0, v2 = 0;
-      const double* cd = s_cam + kCamLds * cs;
-      if (valid) {
-        mf_geom(cd, rec[0], rec[1], rec[2], geo);
-        mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
-        v0 = geo.E[0] * u0 + geo.E[3] * u1;
-        v1 = geo.E[1] * u0 + geo.E[4] * u1;
-        v2 = geo.E[2] * u0 + geo.E[5] * u1;
-      }
-      // segmented inclusive scan over the lanes of each point (a point's lanes are contiguous)
-      for (int d = 1; d < maxrun; d <<= 1) {
-        const int src = (lane - d) << 2;   // byte address of the source lane (wraps harmlessly: masked by pos >= d)
-        const double t0 = lane_read(v0, src), t1 = lane_read(v1, src), t2 = lane_read(v2, src);
-        const bool in = pos >= d;
-        v0 += in ? t0 : 0.0; v1 += in ? t1 : 0.0; v2 += in ? t2 : 0.0;
-      }
-      // total of the run sits in its last lane
-      const int last = (lane - pos + cnt - 1) << 2;
-      const double a0 = lane_read(v0, last), a1 = lane_read(v1, last), a2 = lane_read(v2, last);
-      if (valid) {
-        // rec[3..8] = diag(sp) C^-1 diag(sp);  y = -that * sum E'u
-        const double y0 = -(rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
-        const double y1 = -(rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
-        const double y2 = -(rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
-        const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
-        const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
-        double o[9];
-        mf_transpose(geo, rec[0], rec[1], rec[2], w0, w1, o);
-        // consecutive points go to different accumulator copies: lanes of one ds_add rarely share an address
-        double* dst = s_acc + (pl & (kAccCopies - 1)) * acc_stride + 9 * cs;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(dst + k, o[k]);
-      }
+    bool small = false;
+    if (tid < t.ncs) {
+      mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, x);
+      small = s_cam[kCamLds * tid + 24] != 0.0;
     }
+    for (int i = tid; i < kAccCopies * t.ncs * 9; i += kChunk) s_acc[i] = 0.0;
+    const int any_small = __syncthreads_or(small);
+    if (any_small) mf_matvec_tile<true>(t, idx, wl, ptrec, s_cam, s_acc);
+    else mf_matvec_tile<false>(t, idx, wl, ptrec, s_cam, s_acc);
     __syncthreads();  // every wave's LDS atomics have landed
+    const int acc_stride = t.ncs * 9;
     for (int i = tid; i < acc_stride; i += kChunk) {
       double v = s_acc[i];
 #pragma unroll
@@ -382,8 +431,8 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
     for (int q = wv; q < nwl; q += 4) {
       const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
       const int32_t w = idx[slot];
-      const int maxrun = wl[(t.slot0 >> 6) + q].y;
-      const int gpt0 = grps[t.grp0 + (q >> 2)].pt0;
+      const int2 wq = wl[(t.slot0 >> 6) + q];   // {first point of the enclosing chunk, longest point run}
+      const int maxrun = wq.y, gpt0 = wq.x;
       const bool valid = w >= 0;
       const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
       const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
@@ -534,8 +583,8 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
     for (int q = wv; q < nwl; q += 4) {
       const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
       const int32_t w = idx[slot];
-      const int maxrun = wl[(t.slot0 >> 6) + q].y;
-      const int gpt0 = grps[t.grp0 + (q >> 2)].pt0;
+      const int2 wq = wl[(t.slot0 >> 6) + q];   // {first point of the enclosing chunk, longest point run}
+      const int maxrun = wq.y, gpt0 = wq.x;
       const bool valid = w >= 0;
       const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
       const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
