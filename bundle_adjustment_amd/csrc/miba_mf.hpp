@@ -18,7 +18,10 @@
 
 namespace miba {
 
-constexpr int kAccCopies = 4;  // copies of the per-tile camera accumulators (fewer same-address LDS atomics)
+#ifndef MIBA_ACC_COPIES
+#define MIBA_ACC_COPIES 4
+#endif
+constexpr int kAccCopies = MIBA_ACC_COPIES;  // copies of the per-tile camera accumulators (fewer same-address LDS atomics)
 constexpr int kCamLds = 25;  // odd stride: conflict-free ds_read_b64 across camera slots
 
 // [R 0..8 | t 9..11 | f k1 k2 12..14 | m 15..17 | tau 18..20 | xi 21..23 | small 24]
@@ -134,6 +137,33 @@ __device__ __forceinline__ double lane_read(double v, int lane_byte_addr) {
   return __hiloint2double(hi, lo);
 }
 
+// value of v in lane - 1 (0 in lane 0): wavefront shift through DPP, on the VALU instead of the LDS crossbar
+__device__ __forceinline__ double lane_shr1(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// segmented inclusive scan of three values over the lanes of each point (a point's lanes are contiguous, pos =
+// position in the run, maxrun = longest run in the wavelet, wave-uniform).  Steps 1 and 2 shift through DPP.
+__device__ __forceinline__ void mf_seg_scan3(double& v0, double& v1, double& v2, int lane, int pos, int maxrun) {
+  if (maxrun > 1) {
+    const double in = (pos >= 1) ? 1.0 : 0.0;
+    v0 = fma(lane_shr1(v0), in, v0); v1 = fma(lane_shr1(v1), in, v1); v2 = fma(lane_shr1(v2), in, v2);
+  }
+  if (maxrun > 2) {
+    const double in = (pos >= 2) ? 1.0 : 0.0;
+    v0 = fma(lane_shr1(lane_shr1(v0)), in, v0); v1 = fma(lane_shr1(lane_shr1(v1)), in, v1);
+    v2 = fma(lane_shr1(lane_shr1(v2)), in, v2);
+  }
+  for (int d = 4; d < maxrun; d <<= 1) {
+    const int src = (lane - d) << 2;   // byte address of the source lane (wraps harmlessly: masked by pos >= d)
+    const double t0 = lane_read(v0, src), t1 = lane_read(v1, src), t2 = lane_read(v2, src);
+    const double in = (pos >= d) ? 1.0 : 0.0;
+    v0 = fma(t0, in, v0); v1 = fma(t1, in, v1); v2 = fma(t2, in, v2);
+  }
+}
+
 // gather of the first 9 doubles of a point record (lanes of one point read the same 72 bytes)
 __device__ __forceinline__ void mf_load_rec9(double* rec, const double* __restrict__ ptrec, int32_t w, int chunk_pt0) {
   const int pl = (w >= 0) ? (w & 0xFF) : 0;   // pad lanes read the chunk's first point: no branch, finite data
@@ -185,13 +215,7 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
     double v0 = valid ? geo.E[0] * u0 + geo.E[3] * u1 : 0.0;
     double v1 = valid ? geo.E[1] * u0 + geo.E[4] * u1 : 0.0;
     double v2 = valid ? geo.E[2] * u0 + geo.E[5] * u1 : 0.0;
-    // segmented inclusive scan over the lanes of each point (a point's lanes are contiguous)
-    for (int d = 1; d < maxrun; d <<= 1) {
-      const int src = (lane - d) << 2;   // byte address of the source lane (wraps harmlessly: masked by pos >= d)
-      const double t0 = lane_read(v0, src), t1 = lane_read(v1, src), t2 = lane_read(v2, src);
-      const double in = (pos >= d) ? 1.0 : 0.0;
-      v0 = fma(t0, in, v0); v1 = fma(t1, in, v1); v2 = fma(t2, in, v2);
-    }
+    mf_seg_scan3(v0, v1, v2, lane, pos, maxrun);
     // total of the run sits in its last lane
     const int last = (lane - pos + cnt - 1) << 2;
     const double a0 = lane_read(v0, last), a1 = lane_read(v1, last), a2 = lane_read(v2, last);

@@ -21,7 +21,7 @@ namespace miba {
 constexpr int kChunk = 256;        // observation slots per chunk = threads per block
 constexpr int kWave = 64;          // a point never straddles a 64-slot wavelet (one wavefront)
 constexpr int kMaxCamSlots = 64;   // distinct cameras per (non-giant) tile: LDS accumulator rows
-constexpr int kMaxChunksPerTile = 4;   // default; MIBA_TILE_CHUNKS overrides (1..16)
+constexpr int kMaxChunksPerTile = 8;   // default; MIBA_TILE_CHUNKS overrides (1..16)
 constexpr int kJComp = 26;         // doubles stored per observation: F 18, E 6, r 2
 constexpr int kPtRec = 12;        // per-point record: X 0..2 | W = diag(sp) C^-1 diag(sp) 3..8 | zg = sp.(C^-1 g) 9..11
 constexpr int kCamTabStride = 48;  // per-camera table row (R 9, t 3, f k1 k2, pad, dR 27, pad)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiba.so")
+LIB_PATH = os.environ.get("MIBA_LIB", os.path.join(_HERE, "libmiba.so"))   # MIBA_LIB: kernel-variant experiments
 
 (DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR,
  ITERATIVE_SCHUR, CGNR) = range(7)
