@@ -22,7 +22,18 @@ namespace miba {
 #define MIBA_ACC_COPIES 4
 #endif
 constexpr int kAccCopies = MIBA_ACC_COPIES;  // copies of the per-tile camera accumulators (fewer same-address LDS atomics)
-constexpr int kCamLds = 25;  // odd stride: conflict-free ds_read_b64 across camera slots
+constexpr int kCamLds = 26;  // camera record stride in LDS: 13 x 16 bytes, read with ds_read_b128 (256 B/clk; the
+                             // ds_read2_b64 the compiler would otherwise form runs at half that on gfx950)
+
+// one camera record from LDS into registers: 13 ds_read_b128
+__device__ __forceinline__ void mf_read_cam(double* cd /*[kCamLds]*/, const double* s_cam, int cs) {
+  const double2* p = reinterpret_cast<const double2*>(s_cam) + (kCamLds / 2) * cs;
+#pragma unroll
+  for (int k = 0; k < kCamLds / 2; ++k) {
+    const double2 v = p[k];
+    cd[2 * k] = v.x; cd[2 * k + 1] = v.y;
+  }
+}
 
 // [R 0..8 | t 9..11 | f k1 k2 12..14 | m 15..17 | tau 18..20 | xi 21..23 | small 24]
 __device__ __forceinline__ void mf_stage_cam(double* dst, int cam, const double* __restrict__ ct,
@@ -207,9 +218,8 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
     const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
     MfGeo geo;
     double u0, u1;
-    int cam_off = kCamLds * cs;
-    asm volatile("" : "+v"(cam_off));   // one LDS base address; the 25 reads use immediate offsets
-    const double* cd = s_cam + cam_off;
+    double cd[kCamLds];
+    mf_read_cam(cd, s_cam, cs);
     mf_geom<SMALL>(cd, rec[0], rec[1], rec[2], geo);
     mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
     double v0 = valid ? geo.E[0] * u0 + geo.E[3] * u1 : 0.0;
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
                                                    const double* __restrict__ ptrec /*[npt][kPtRec]*/,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
                                                    const Ctl* __restrict__ ctl) {
-  __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
+  __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
   __shared__ double s_acc[GIANT ? 1 : kAccCopies * kMaxCamSlots * 9];
   __shared__ double s4[4];
   if (ctl->done) return;
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
                                                  double* __restrict__ Cinv, double* __restrict__ gp, double* __restrict__ dgp,
                                                  double* __restrict__ ptrec, double* __restrict__ slab /*[rows][64]*/,
                                                  double* __restrict__ partial_cost, Ctl* __restrict__ ctl) {
-  __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
+  __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
   __shared__ double s_acc[GIANT ? 1 : kMaxCamSlots * 63];
   __shared__ double s4[4];
   const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
@@ -470,7 +480,9 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         s0 = sp[3 * p]; s1 = sp[3 * p + 1]; s2 = sp[3 * p + 2];
         const size_t chunk = slot / kChunk, l = slot % kChunk;
         const double ox = oxy[chunk * (2 * kChunk) + l], oy = oxy[chunk * (2 * kChunk) + kChunk + l];
-        mf_blocks(s_cam + kCamLds * cs, x0, x1, x2, ox, oy, F, E, r0, r1);
+        double cd[kCamLds];
+        mf_read_cam(cd, s_cam, cs);
+        mf_blocks(cd, x0, x1, x2, ox, oy, F, E, r0, r1);
         cost += r0 * r0 + r1 * r1;
         v[0] = E[0] * E[0] + E[3] * E[3];
         v[1] = E[1] * E[0] + E[4] * E[3];
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
                                                     const double* __restrict__ ptrec, const double* __restrict__ yc,
                                                     double* __restrict__ yp, double* __restrict__ Xc,
                                                     double* __restrict__ partial) {
-  __shared__ double s_cam[GIANT ? 1 : kMaxCamSlots * kCamLds];
+  __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
   __shared__ double s4[4];
   const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
   const Tile t = tiles[tile_id];
@@ -622,7 +634,8 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         const double* rp = ptrec + (size_t)kPtRec * p;
 #pragma unroll
         for (int k = 0; k < kPtRec; ++k) rec[k] = rp[k];
-        const double* cd = s_cam + kCamLds * cs;
+        double cd[kCamLds];
+        mf_read_cam(cd, s_cam, cs);
         mf_geom(cd, rec[0], rec[1], rec[2], geo);
         mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
         v0 = geo.E[0] * u0 + geo.E[3] * u1;
