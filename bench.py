@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (fp64 FMA at full vector rate)
+MF_FLOP_PER_SLOT = 205.0         # fp64 flops per observation slot of k_mf_matvec<false>, counted from its ISA
 
 
 def main():
@@ -104,23 +106,54 @@ def main():
 
     timed = [r for r in its if args.warmup < r["iteration"] <= total]
     n_cg = sum(r["linear_solver_iterations"] for r in timed)
-    # dominant kernel: K3 implicit-Schur mat-vec. Algorithmic bytes per launch:
-    # 196*o + 48*m + 144*n with this rank's observations o and points m, n cameras.
+    mf = os.environ.get("MIBA_MF", "1") != "0"
+    # Algorithmic bytes per launch (DESIGN.md "Kernels"): o = this rank's observations, m = its points, n = cameras.
     o_loc, m_loc = kt["n_obs_local"], kt["n_pt_local"]
-    k3_bytes = 196.0 * o_loc + 48.0 * m_loc + 144.0 * n_cam
+    if mf:
+        # matrix-free kernels: 4-byte index word (+16-byte measurement where the residual is needed) per observation,
+        # the point record per point, camera vectors in and out
+        alg = {miba.K_EVAL_JAC: ("K1_eval_jac (miba_evaluate only)", 228.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
+               miba.K_EVAL_COST: ("K1p_eval_cost", 20.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
+               miba.K_SCHUR_INIT: ("K2mf_schur_init", 20.0 * o_loc + 240.0 * m_loc + 584.0 * n_cam),
+               miba.K_SCHUR_MATVEC: ("K3mf_schur_matvec", 4.0 * o_loc + 72.0 * m_loc + 144.0 * n_cam),
+               miba.K_BACKSUB: ("K4mf_backsub", 20.0 * o_loc + 168.0 * m_loc + 72.0 * n_cam)}
+    else:
+        alg = {miba.K_EVAL_JAC: ("K1_eval_jac", 228.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
+               miba.K_EVAL_COST: ("K1p_eval_cost", 20.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
+               miba.K_SCHUR_INIT: ("K2_schur_init", 212.0 * o_loc + 72.0 * m_loc + 720.0 * n_cam),
+               miba.K_SCHUR_MATVEC: ("K3_schur_matvec", 196.0 * o_loc + 48.0 * m_loc + 144.0 * n_cam),
+               miba.K_BACKSUB: ("K4_backsub", 212.0 * o_loc + 96.0 * m_loc + 72.0 * n_cam)}
+    k3_bytes = alg[miba.K_SCHUR_MATVEC][1]
     k3_n = kt["launches"][miba.K_SCHUR_MATVEC]
     k3_ms = kt["total_ms"][miba.K_SCHUR_MATVEC] / max(1, k3_n)
     achieved = k3_bytes / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
     kern = {}
-    names = {miba.K_EVAL_JAC: ("K1_eval_jac", 228.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
-             miba.K_EVAL_COST: ("K1p_eval_cost", 20.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
-             miba.K_SCHUR_INIT: ("K2_schur_init", 212.0 * o_loc + 72.0 * m_loc + 720.0 * n_cam),
-             miba.K_SCHUR_MATVEC: ("K3_schur_matvec", k3_bytes),
-             miba.K_BACKSUB: ("K4_backsub", 212.0 * o_loc + 96.0 * m_loc + 72.0 * n_cam)}
-    for kid, (nm, by) in names.items():
+    for kid, (nm, by) in alg.items():
         n = kt["launches"][kid]
         ms = kt["total_ms"][kid] / max(1, n)
         kern[nm] = {"launches": n, "avg_ms": round(ms, 4), "algorithmic_GBs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+    # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if mf and args.gpus == 1 and args.config == "final-13682" and os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh).get("k_mf_matvec<false>", {}).get("traffic_bytes_per_launch")
+    roof = {"bound": "hbm", "kernel": "k_mf_matvec<false> (K3-mf)" if mf else "k_schur_matvec<0> (K3)", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": k3_ms,
+            "launches": k3_n, "algorithmic_bytes_per_launch": k3_bytes}
+    if mf:
+        # The matrix-free product trades HBM bytes for fp64 work: it is bound by the vector fp64 / LDS pipes, not by
+        # HBM.  Two extra views: the fp64 rate against the vector peak, and the bytes a stored-Jacobian product
+        # (196 o + 48 m + 144 n) would have had to stream in the same time.
+        flop = MF_FLOP_PER_SLOT * kt["n_slots"]
+        stored = 196.0 * o_loc + 48.0 * m_loc + 144.0 * n_cam
+        roof["valu_f64"] = {"flop_per_launch": flop, "achieved": flop / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0,
+                            "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flop / (k3_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if k3_ms > 0 else 0.0}
+        roof["stored_jacobian_form"] = {"bytes_per_launch": stored,
+                                        "equivalent_GBs": stored / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0,
+                                        "note": "bytes a stored-J product streams per launch; at 8 TB/s that alone takes %.3f ms"
+                                                % (stored / 8e12 * 1e3)}
 
     out = {
         "metric": "LM iters/sec on BAL Final-13682",
@@ -137,15 +170,14 @@ def main():
         "data": "synthetic",
         "config": {"workload": "synthetic BAL-format stand-in for %s: %d cameras / %d points / %d observations, seed %d, "
                                "initial state = ground truth + N(0,%g) on camera rot/trans + N(0,%g) on points; "
-                               "LM + ITERATIVE_SCHUR (implicit Schur, JACOBI preconditioner, eta=%g)"
-                               % (args.config, n_cam, n_pt, n_obs, seed, args.sigma_cam, args.sigma_x, args.eta),
+                               "LM + ITERATIVE_SCHUR (implicit Schur, JACOBI preconditioner, eta=%g); %s kernels"
+                               % (args.config, n_cam, n_pt, n_obs, seed, args.sigma_cam, args.sigma_x, args.eta,
+                                  "matrix-free" if mf else "stored-Jacobian"),
                    "pcg_iterations_in_timed_steps": n_cg,
                    "successful_steps_in_timed_steps": sum(r["step_is_successful"] for r in timed),
                    "cost_first": its[0]["cost"], "cost_last": summ["final_cost"],
                    "parallelism": "points sharded over %d GPU(s), cameras replicated, RCCL all-reduce" % args.gpus},
-        "roofline": {"bound": "hbm", "kernel": "k_schur_matvec (K3)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "avg_launch_ms": k3_ms, "launches": k3_n, "algorithmic_bytes_per_launch": k3_bytes},
+        "roofline": roof,
         "kernels": kern,
         "setup": {"generate_s": round(t_gen, 2), "set_problem_s": round(t_setup, 2), "tiles": kt["n_tiles"],
                   "slots": kt["n_slots"]},
