@@ -228,3 +228,61 @@ def test_giant_and_tiny_tracks(oracle):
     assert rel(out["Sv"], refl["Sv"]) <= 1e-10
     assert rel(out["y_pt"], refl["y_pt"]) <= 1e-6
     assert abs(out["model_cost_change"] - refl["model_cost_change"]) <= 1e-8 * abs(refl["model_cost_change"])
+
+
+def _solve_with_env(pr, cams0, pts0, env, n_it=8):
+    """One LM run with environment knobs that libmiba reads at create / set_problem time."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = make_solver(pr, cams0, pts0)
+        out = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR),
+                            probe=np.random.default_rng(5).normal(size=(cams0.shape[0], 9)))
+        its, summ = s.solve(miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, max_num_iterations=n_it,
+                                                 function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
+        s.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return out, its, summ
+
+
+def test_matrix_free_matches_stored_jacobian(medium):
+    """The default matrix-free kernels (K2-mf/K3-mf/K4-mf) against the stored-Jacobian kernels (MIBA_MF=0):
+    same operator, same right-hand side, same PCG iteration counts, same LM trajectory."""
+    pr, cams0, pts0 = medium
+    a, ia, sa = _solve_with_env(pr, cams0, pts0, {"MIBA_MF": "1"})
+    b, ib, sb = _solve_with_env(pr, cams0, pts0, {"MIBA_MF": "0"})
+    assert rel(a["rhs"], b["rhs"]) <= 1e-11
+    assert rel(a["Sv"], b["Sv"]) <= 1e-11
+    assert a["n_cg"] == b["n_cg"]
+    assert rel(a["y_cam"], b["y_cam"]) <= 1e-9 and rel(a["y_pt"], b["y_pt"]) <= 1e-9
+    assert abs(a["model_cost_change"] - b["model_cost_change"]) <= 1e-10 * abs(b["model_cost_change"])
+    for x, y in zip(ia[:5], ib[:5]):
+        assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
+        assert x["linear_solver_iterations"] == y["linear_solver_iterations"]
+    assert abs(sa["final_cost"] - sb["final_cost"]) <= REL_COST * sb["final_cost"]
+
+
+@pytest.mark.parametrize("tile_chunks", ["1", "3", "16"])
+def test_tile_size_does_not_change_results(medium, tile_chunks):
+    """MIBA_TILE_CHUNKS only changes how observations are grouped into workgroup tiles."""
+    pr, cams0, pts0 = medium
+    a, ia, sa = _solve_with_env(pr, cams0, pts0, {})
+    b, ib, sb = _solve_with_env(pr, cams0, pts0, {"MIBA_TILE_CHUNKS": tile_chunks})
+    assert rel(a["Sv"], b["Sv"]) <= 1e-11 and rel(a["rhs"], b["rhs"]) <= 1e-11
+    assert abs(sa["final_cost"] - sb["final_cost"]) <= REL_COST * sb["final_cost"]
+
+
+def test_rccl_path_single_rank(medium):
+    """MIBA_FORCE_RCCL=1 builds a one-rank RCCL communicator, so every all-reduce of the multi-GPU path and the
+    non-fused p.q reduction run; results must equal the communicator-free path."""
+    pr, cams0, pts0 = medium
+    a, ia, sa = _solve_with_env(pr, cams0, pts0, {})
+    b, ib, sb = _solve_with_env(pr, cams0, pts0, {"MIBA_FORCE_RCCL": "1"})
+    assert rel(a["Sv"], b["Sv"]) <= 1e-12 and rel(a["y_cam"], b["y_cam"]) <= 1e-9
+    assert [r["linear_solver_iterations"] for r in ia[:5]] == [r["linear_solver_iterations"] for r in ib[:5]]
+    assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
