@@ -56,7 +56,7 @@ struct Plan {
   std::vector<int32_t> pt_first;         // [n_pt] first slot of sorted point
   std::vector<int32_t> pt_count;         // [n_pt]
   std::vector<int32_t> tile_cams;        // per (tile, cam slot): global camera id
-  std::vector<int32_t> wl_pt0, wl_npt;   // per 64-slot wavelet: first sorted point that starts in it, longest run
+  std::vector<int32_t> wl_npt;           // per 64-slot wavelet: longest point run
   int64_t n_slots = 0;
   // sharding: rank r owns tiles [shard_tile[r], shard_tile[r+1])
   std::vector<int64_t> shard_tile;
@@ -112,63 +112,87 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   for (int32_t s = 0; s < n_act; ++s)
     std::stable_sort(obs_sorted.begin() + off[s], obs_sorted.begin() + off[s + 1],
                      [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
-  // --- tiling
+  // --- tiling, phase 1: cut the point sequence into tiles.  A tile holds whole points, at most kMaxCamSlots
+  // distinct cameras and about max_chunks chunks of observations; a giant point (more observations than a
+  // wavefront) is a tile of its own.
+  if ((P.n_valid + (int64_t)n_act * kChunk) >= (int64_t)INT32_MAX) return -6;  // slots are int32
+  struct Span { int32_t s0, s1, giant; };
+  std::vector<Span> spans;
+  {
+    std::vector<int32_t> stamp(n_cam, -1);
+    const int64_t cap = (int64_t)max_chunks * kChunk - (max_chunks > 1 ? kWave : 0);
+    int32_t open_s0 = -1, ncs = 0, span_id = 0;
+    int64_t used = 0;
+    auto close = [&](int32_t s_end) {
+      if (open_s0 >= 0) spans.push_back(Span{open_s0, s_end, 0});
+      open_s0 = -1;
+    };
+    for (int32_t s = 0; s < n_act; ++s) {
+      const int64_t a = off[s], b = off[s + 1];
+      const int32_t L = (int32_t)(b - a);
+      if (L > kWave) {
+        close(s);
+        spans.push_back(Span{s, s + 1, 1});
+        continue;
+      }
+      auto count_new = [&]() {
+        int add = 0;
+        int32_t prev = -1;
+        for (int64_t j = a; j < b; ++j) {
+          const int32_t c = obs_cam[obs_sorted[j]];
+          if (c != prev && stamp[c] != span_id) ++add;
+          prev = c;
+        }
+        return add;
+      };
+      if (open_s0 >= 0) {
+        const int add = count_new();
+        if (ncs + add > kMaxCamSlots || used + L > cap) close(s);
+      }
+      if (open_s0 < 0) { open_s0 = s; ++span_id; ncs = 0; used = 0; }
+      for (int64_t j = a; j < b; ++j) {
+        const int32_t c = obs_cam[obs_sorted[j]];
+        if (stamp[c] != span_id) { stamp[c] = span_id; ++ncs; }
+      }
+      used += L;
+    }
+    close(n_act);
+  }
+  // --- phase 2: lay every tile out.  Inside a tile the point order is free, so its points are packed
+  // first-fit-decreasing into 64-slot wavelets (a point never straddles a wavelet): little padding, and points
+  // of similar length share a wavelet, which keeps the segmented scans of the kernels short.  Points are
+  // renumbered in layout order.
+  std::vector<int32_t> new_orig;   // layout-order point -> caller's point id
+  new_orig.reserve(n_act);
   P.pt_first.assign(n_act, 0);
   P.pt_count.assign(n_act, 0);
   std::vector<int32_t> stamp(n_cam, -1), slot_of(n_cam, 0);
   int64_t slots = 0;
-  bool tile_open = false, chunk_open = false;
-  Tile T{};
-  Group G{};
-  int chunk_fill = 0;
-  auto pad_chunk = [&]() {
-    while (slots % kChunk) { P.idx.push_back(-1); P.ocam.push_back(0); P.slot_orig.push_back(-1); ++slots; }
+  auto pad_to = [&](int64_t mult) {
+    while (slots % mult) { P.idx.push_back(-1); P.ocam.push_back(0); P.slot_orig.push_back(-1); ++slots; }
   };
-  auto close_chunk = [&]() {
-    if (!chunk_open) return;
-    pad_chunk();
-    P.groups.push_back(G);
-    T.ngrp++;
-    chunk_open = false;
-    chunk_fill = 0;
-  };
-  auto close_tile = [&]() {
-    close_chunk();
-    if (!tile_open) return;
-    T.nslot = (int32_t)(slots - T.slot0);
-    P.tiles.push_back(T);
-    tile_open = false;
-  };
-  auto open_tile = [&](int giant) {
-    T = Tile{};
+  std::vector<int32_t> order, bin_free, bin_of;
+  std::vector<std::vector<int32_t>> bins;
+  for (size_t ti = 0; ti < spans.size(); ++ti) {
+    const Span sp = spans[ti];
+    Tile T{};
     T.grp0 = (int32_t)P.groups.size();
     T.cam0 = (int32_t)P.tile_cams.size();
-    T.giant = giant;
+    T.giant = sp.giant;
     T.slot0 = (int32_t)slots;
-    tile_open = true;
-  };
-  auto open_chunk = [&](int32_t pt0) {
-    G = Group{};
-    G.chunk0 = (int32_t)(slots / kChunk);
-    G.nchunk = 1;
-    G.pt0 = pt0;
-    chunk_open = true;
-    chunk_fill = 0;
-  };
-  if ((P.n_valid + (int64_t)n_act * kChunk) >= (int64_t)INT32_MAX) return -6;  // slots are int32
-  for (int32_t s = 0; s < n_act; ++s) {
-    const int64_t a = off[s], b = off[s + 1];
-    const int32_t L = (int32_t)(b - a);
-    if (L > kWave) {
-      // giant point (more observations than a wavefront): a tile of its own, one camera slot per
-      // observation, no LDS accumulation
-      close_tile();
-      open_tile(1);
-      open_chunk(s);
-      G.npt = 1;
+    if (sp.giant) {
+      // one camera slot (= slab row) per observation, no LDS accumulation
+      const int32_t s = sp.s0;
+      const int64_t a = off[s], b = off[s + 1];
+      const int32_t L = (int32_t)(b - a);
+      const int32_t np = (int32_t)new_orig.size();
+      Group G{};
+      G.chunk0 = (int32_t)(slots / kChunk);
       G.nchunk = (L + kChunk - 1) / kChunk;
-      P.pt_first[s] = (int32_t)slots;
-      P.pt_count[s] = L;
+      G.pt0 = np; G.npt = 1;
+      P.pt_first[np] = (int32_t)slots;
+      P.pt_count[np] = L;
+      new_orig.push_back(P.pt_orig[s]);
       for (int64_t j = a; j < b; ++j) {
         const int64_t i = obs_sorted[j];
         P.idx.push_back(0);
@@ -177,63 +201,73 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
         P.tile_cams.push_back(obs_cam[i]);
         ++slots;
       }
+      pad_to(kChunk);
       T.ncs = L;
-      close_tile();
-      continue;
-    }
-    // distinct new cameras this point would add to the open tile
-    const int32_t tile_id = (int32_t)P.tiles.size();
-    int add = 0;
-    if (tile_open) {
-      int32_t prev = -1;
-      for (int64_t j = a; j < b; ++j) {
-        const int32_t c = obs_cam[obs_sorted[j]];
-        if (c != prev && stamp[c] != tile_id) ++add;
-        prev = c;
+      P.groups.push_back(G);
+      T.ngrp = 1;
+    } else {
+      const int32_t np_t = sp.s1 - sp.s0;
+      order.resize(np_t);
+      for (int32_t k = 0; k < np_t; ++k) order[k] = sp.s0 + k;
+      std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
+      bins.clear(); bin_free.clear();
+      size_t first_open = 0;   // bins before it are full
+      for (int32_t s : order) {
+        const int32_t L = (int32_t)(off[s + 1] - off[s]);
+        size_t bsel = bins.size();
+        for (size_t bi = first_open; bi < bins.size(); ++bi)
+          if (bin_free[bi] >= L) { bsel = bi; break; }
+        if (bsel == bins.size()) { bins.emplace_back(); bin_free.push_back(kWave); }
+        bins[bsel].push_back(s);
+        bin_free[bsel] -= L;
+        while (first_open < bins.size() && bin_free[first_open] == 0) ++first_open;
       }
-      if (T.ncs + add > kMaxCamSlots) close_tile();
-    }
-    if (tile_open && chunk_open) {
-      const int pos = (int)(slots - (int64_t)G.chunk0 * kChunk);
-      const int padw = ((pos % kWave) + L > kWave) ? kWave - (pos % kWave) : 0;
-      if (pos + padw + L > kChunk || G.npt >= 256) {
-        close_chunk();
-        if (T.ngrp >= max_chunks) close_tile();
+      const int32_t tid = (int32_t)ti;
+      for (size_t b0 = 0; b0 < bins.size(); b0 += 4) {
+        Group G{};
+        G.chunk0 = (int32_t)(slots / kChunk);
+        G.nchunk = 1;
+        G.pt0 = (int32_t)new_orig.size();
+        for (size_t bi = b0; bi < std::min(b0 + 4, bins.size()); ++bi) {
+          for (int32_t s : bins[bi]) {
+            const int64_t a = off[s], b = off[s + 1];
+            const int32_t L = (int32_t)(b - a);
+            const int32_t np = (int32_t)new_orig.size();
+            const int32_t pl = np - G.pt0;
+            P.pt_first[np] = (int32_t)slots;
+            P.pt_count[np] = L;
+            new_orig.push_back(P.pt_orig[s]);
+            for (int64_t j = a; j < b; ++j) {
+              const int64_t i = obs_sorted[j];
+              const int32_t c = obs_cam[i];
+              if (stamp[c] != tid) {
+                stamp[c] = tid;
+                slot_of[c] = T.ncs++;
+                P.tile_cams.push_back(c);
+              }
+              // point-in-chunk | camera-slot-in-tile << 8 | position in the point's run << 16 | run length << 23
+              P.idx.push_back(pl | (slot_of[c] << 8) | ((int32_t)(j - a) << 16) | (L << 23));
+              P.ocam.push_back(c);
+              P.slot_orig.push_back(i);
+              ++slots;
+            }
+            G.npt++;
+          }
+          pad_to(kWave);
+        }
+        pad_to(kChunk);
+        P.groups.push_back(G);
+        T.ngrp++;
       }
     }
-    if (!tile_open) open_tile(0);
-    if (!chunk_open) open_chunk(s);
-    // keep the point inside one 64-slot wavelet
-    if ((int)(slots % kWave) + L > kWave)
-      while (slots % kWave) { P.idx.push_back(-1); P.ocam.push_back(0); P.slot_orig.push_back(-1); ++slots; }
-    const int32_t tid = (int32_t)P.tiles.size();
-    P.pt_first[s] = (int32_t)slots;
-    P.pt_count[s] = L;
-    const int32_t pl = G.npt;
-    for (int64_t j = a; j < b; ++j) {
-      const int64_t i = obs_sorted[j];
-      const int32_t c = obs_cam[i];
-      if (stamp[c] != tid) {
-        stamp[c] = tid;
-        slot_of[c] = T.ncs++;
-        P.tile_cams.push_back(c);
-      }
-      // point-in-chunk | camera-slot-in-tile << 8 | position in the point's run << 16 | run length << 23
-      P.idx.push_back(pl | (slot_of[c] << 8) | ((int32_t)(j - a) << 16) | (L << 23));
-      P.ocam.push_back(c);
-      P.slot_orig.push_back(i);
-      ++slots;
-    }
-    G.npt++;
-    chunk_fill += L;
+    T.nslot = (int32_t)(slots - T.slot0);
+    P.tiles.push_back(T);
   }
-  close_tile();
+  P.pt_orig.swap(new_orig);
   P.n_slots = slots;
-  P.wl_pt0.assign((size_t)(slots / kWave) + 1, 0);
   P.wl_npt.assign((size_t)(slots / kWave) + 1, 0);
-  for (int32_t s = n_act - 1; s >= 0; --s) {
+  for (int32_t s = 0; s < n_act; ++s) {
     const size_t wq = (size_t)(P.pt_first[s] / kWave);
-    P.wl_pt0[wq] = s;
     P.wl_npt[wq] = std::max(P.wl_npt[wq], P.pt_count[s]);   // longest run in the wavelet
   }
   // --- shard tiles by cumulative slot count
