@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (fp64 FMA at full vector rate)
-MF_FLOP_PER_SLOT = 205.0         # fp64 flops per observation slot of k_mf_matvec<false>, counted from its ISA
+MF_FLOP_PER_SLOT = 205.0         # fp64 flops per observation slot of k_mf_matvec, counted from its ISA
 
 
 def main():
@@ -137,8 +137,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
     if mf and args.gpus == 1 and args.config == "final-13682" and os.path.exists(tpath):
         with open(tpath) as fh:
-            traffic = json.load(fh).get("k_mf_matvec<false>", {}).get("traffic_bytes_per_launch")
-    roof = {"bound": "hbm", "kernel": "k_mf_matvec<false> (K3-mf)" if mf else "k_schur_matvec<0> (K3)", "achieved": achieved,
+            traffic = json.load(fh).get("k_mf_matvec", {}).get("traffic_bytes_per_launch")
+    roof = {"bound": "hbm", "kernel": "k_mf_matvec (K3-mf)" if mf else "k_schur_matvec<0> (K3)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": k3_ms,
             "launches": k3_n, "algorithmic_bytes_per_launch": k3_bytes}
     if mf:

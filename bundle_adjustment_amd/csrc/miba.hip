@@ -69,6 +69,11 @@ struct miba_handle_s {
   double *d_oxy = nullptr, *d_cam = nullptr, *d_cam_cand = nullptr, *d_ct = nullptr, *d_sc = nullptr;
   double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
+  // camera-major copy of the local observations (K2-mf camera side): segments of one camera each
+  int4* d_seg = nullptr; int32_t* d_cmo_pt = nullptr; double2* d_cmo_xy = nullptr; int32_t* d_cam_seg_off = nullptr;
+  double *d_slabB = nullptr, *d_xz = nullptr;
+  int32_t n_seg = 0;
+  bool k2_onepass = false;                        // MIBA_K2_ONEPASS=1: K2-mf with LDS-atomic camera rows in one pass
   int32_t n_giant = 0;
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
@@ -252,20 +257,40 @@ constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 +
 int mf_init_launch(miba_handle h, double inv_r, const miba_options* o) {
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
-    hipLaunchKernelGGL(k_mf_init<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
-                       h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm, h->d_X,
-                       h->d_sp, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp, h->d_dgp, h->d_ptrec,
-                       h->d_slab64, h->d_part_tile, h->d_ctl);
-    if (h->n_giant)
-      hipLaunchKernelGGL(k_mf_init<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
-                         h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm, h->d_X, h->d_sp,
-                         inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp, h->d_dgp, h->d_ptrec, h->d_slab64,
-                         h->d_part_tile, h->d_ctl);
+#define MIBA_INIT_ARGS(list)                                                                                              \
+  h->d_tiles, list, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm,   \
+      h->d_X, h->d_sp, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp, h->d_dgp, h->d_ptrec,            \
+      h->d_slab64, h->d_xz, h->d_part_tile, h->d_ctl
+    if (h->k2_onepass) {
+      hipLaunchKernelGGL((k_mf_init<false, true>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
+                         MIBA_INIT_ARGS((const int32_t*)nullptr));
+      if (h->n_giant)
+        hipLaunchKernelGGL((k_mf_init<true, true>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
+    } else {
+      // point side (wavelets), then camera side over the camera-major copy of the observations
+      hipLaunchKernelGGL((k_mf_init<false, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
+                         MIBA_INIT_ARGS((const int32_t*)nullptr));
+      if (h->n_giant)
+        hipLaunchKernelGGL((k_mf_init<true, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
+      if (h->n_seg)
+        hipLaunchKernelGGL(k_mf_camrows, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                           h->d_ct, h->d_cm, h->d_xz, h->d_slabB);
+    }
+#undef MIBA_INIT_ARGS
   }
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
   HIPCHK(h, hipGetLastError());
   return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
+}
+
+// camera sums of K2: rows of the tile slab (stored-J / one-pass K2-mf) or of the segment slab (two-pass K2-mf)
+int cam_reduce64(miba_handle h, const double* sc) {
+  const bool segs = h->use_mf && !h->k2_onepass;
+  hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam,
+                     segs ? h->d_cam_seg_off : h->d_cam_row_off, segs ? h->d_slabB : h->d_slab64, sc, h->d_camacc);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
 }
 
 int schur_init(miba_handle h, double radius, const miba_options* o) {
@@ -282,9 +307,8 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
                        h->d_dgp, h->d_slab64, h->d_ctl, h->d_X, h->d_sp, h->d_ptrec);
   }
   HIPCHK(h, hipGetLastError());
-  hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab64,
-                     h->use_mf ? h->d_sc : (const double*)nullptr, h->d_camacc);
-  HIPCHK(h, hipGetLastError());
+  rc = cam_reduce64(h, h->use_mf ? h->d_sc : (const double*)nullptr);
+  if (rc) return rc;
   rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
   if (rc) return rc;
   const int nb = nblk(h->n_cam, 64);
@@ -311,16 +335,10 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
 int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* part_xy) {
   if (h->use_mf) {
     if (h->n_tiles) {
-      {
-        Timed t(h, MIBA_K_SCHUR_MATVEC);   // the event pair brackets k_mf_matvec<false> alone (bench.py roofline)
-        hipLaunchKernelGGL(k_mf_matvec<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles,
-                           (const int32_t*)nullptr, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct,
-                           h->d_cm, h->d_sc, h->d_sp, h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, ctl);
-      }
-      if (h->n_giant)
-        hipLaunchKernelGGL(k_mf_matvec<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
-                           h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
-                           h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, ctl);
+      Timed t(h, MIBA_K_SCHUR_MATVEC);
+      hipLaunchKernelGGL(k_mf_matvec, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles,
+                         h->d_giant, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm,
+                         h->d_sc, h->d_sp, h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, ctl);
     }
     hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
                        h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->comm ? (double*)nullptr : part_xy,
@@ -364,9 +382,8 @@ int make_scale_mf(miba_handle h, const miba_options* o) {
   if (rc) return rc;
   rc = mf_init_launch(h, 1.0, o);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab64,
-                     (const double*)nullptr, h->d_camacc);
-  HIPCHK(h, hipGetLastError());
+  rc = cam_reduce64(h, nullptr);
+  if (rc) return rc;
   rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
   if (rc) return rc;
   hipLaunchKernelGGL(k_scale_from_acc, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, h->d_camacc, h->d_sc);
@@ -758,6 +775,33 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     pt_rng[q].x = P.pt_first[h->pt_base + q] - (int32_t)h->slot_base;
     pt_rng[q].y = P.pt_count[h->pt_base + q];
   }
+  // camera-major copy of the local observations, cut into segments of at most kSegObs observations of one camera
+  std::vector<int4> segv;
+  std::vector<int32_t> cmo_pt((size_t)(h->n_obs_local ? h->n_obs_local : 1)), cam_seg_off((size_t)p->n_cam + 1, 0);
+  std::vector<double2> cmo_xy((size_t)(h->n_obs_local ? h->n_obs_local : 1));
+  {
+    std::vector<int64_t> coff((size_t)p->n_cam + 1, 0);
+    for (int64_t s = 0; s < h->n_slots; ++s)
+      if (P.slot_orig[h->slot_base + s] >= 0) coff[(size_t)P.ocam[h->slot_base + s] + 1]++;
+    for (int c = 0; c < p->n_cam; ++c) coff[c + 1] += coff[c];
+    std::vector<int64_t> cur(coff.begin(), coff.end() - 1);
+    for (int32_t q = 0; q < h->n_pt; ++q) {   // ascending point order inside every camera
+      const int64_t s0 = pt_rng[q].x;
+      for (int64_t s = s0; s < s0 + pt_rng[q].y; ++s) {
+        const int64_t o = P.slot_orig[h->slot_base + s];
+        const int64_t d = cur[P.ocam[h->slot_base + s]]++;
+        cmo_pt[d] = q;
+        cmo_xy[d] = make_double2(p->obs_xy[2 * o], p->obs_xy[2 * o + 1]);
+      }
+    }
+    for (int c = 0; c < p->n_cam; ++c) {
+      cam_seg_off[c] = (int32_t)segv.size();
+      for (int64_t a = coff[c]; a < coff[c + 1]; a += kSegObs)
+        segv.push_back(make_int4(c, (int)a, (int)std::min<int64_t>(kSegObs, coff[c + 1] - a), 0));
+    }
+    cam_seg_off[p->n_cam] = (int32_t)segv.size();
+    h->n_seg = (int32_t)segv.size();
+  }
 #define ALLOC(ptr, n)                        \
   do {                                       \
     rc = dev_alloc(h, &(ptr), (size_t)(n));  \
@@ -779,6 +823,8 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   for (size_t i = 0; i < tiles.size(); ++i) if (tiles[i].giant) giant.push_back((int32_t)i);
   h->n_giant = (int32_t)giant.size();
   ALLOC(h->d_giant, giant.size());
+  ALLOC(h->d_seg, segv.size()); ALLOC(h->d_cmo_pt, cmo_pt.size()); ALLOC(h->d_cmo_xy, cmo_xy.size());
+  ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_slabB, (size_t)kK2W * segv.size()); ALLOC(h->d_xz, 6 * np);
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
@@ -803,6 +849,10 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   UP(h->d_cam_active, P.cam_active.data(), nc);
   UP(h->d_oxy, oxy.data(), 2 * ns);
   UP(h->d_giant, giant.data(), giant.size());
+  UP(h->d_seg, segv.data(), segv.size());
+  UP(h->d_cmo_pt, cmo_pt.data(), (size_t)h->n_obs_local);
+  UP(h->d_cmo_xy, cmo_xy.data(), (size_t)h->n_obs_local);
+  UP(h->d_cam_seg_off, cam_seg_off.data(), nc + 1);
 #undef ALLOC
 #undef UP
   HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
@@ -817,6 +867,8 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   {
     const char* mf = getenv("MIBA_MF");   // matrix-free kernels are the default; MIBA_MF=0 selects the stored-Jacobian path
     h->use_mf = !(mf && mf[0] == '0');
+    const char* op = getenv("MIBA_K2_ONEPASS");
+    h->k2_onepass = op && op[0] == '1';
   }
   memset(&h->kt, 0, sizeof(h->kt));
   return miba_set_state(h, p->R, p->T, p->K, p->X);

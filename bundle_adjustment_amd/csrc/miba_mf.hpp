@@ -250,7 +250,8 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
 }
 
 template <bool GIANT>
-__global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+__device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, double* s_acc, double* s4,
+                                                   const Tile* __restrict__ tiles,
                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                    const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
                                                    const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
@@ -258,13 +259,8 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
                                                    const double* __restrict__ sc, const double* __restrict__ sp,
                                                    const double* __restrict__ X, const double* __restrict__ Cinv,
                                                    const double* __restrict__ ptrec /*[npt][kPtRec]*/,
-                                                   const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
-                                                   const Ctl* __restrict__ ctl) {
-  __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
-  __shared__ double s_acc[GIANT ? 1 : kAccCopies * kMaxCamSlots * 9];
-  __shared__ double s4[4];
-  if (ctl->done) return;
-  const Tile t = tiles[GIANT ? tile_list[blockIdx.x] : blockIdx.x];
+                                                   const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/) {
+  const Tile t = tiles[tile_index];
   if (!GIANT && t.giant) return;
   const int tid = threadIdx.x;
   if (!GIANT) {
@@ -331,6 +327,31 @@ __global__ __launch_bounds__(256) void k_mf_matvec(const Tile* __restrict__ tile
       }
     }
   }
+}
+
+// K3-mf launch: the first n_giant blocks take the giant tiles of tile_list (they are the slowest blocks, so they
+// start first), block n_giant + i takes tile i (a giant tile returns at once there): the few giant points run
+// beside the ordinary tiles instead of in a launch of their own.
+__global__ __launch_bounds__(256) void k_mf_matvec(int n_giant, const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                   const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                   const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
+                                                   const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
+                                                   const double* __restrict__ ct, const double* __restrict__ cm,
+                                                   const double* __restrict__ sc, const double* __restrict__ sp,
+                                                   const double* __restrict__ X, const double* __restrict__ Cinv,
+                                                   const double* __restrict__ ptrec /*[npt][kPtRec]*/,
+                                                   const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
+                                                   const Ctl* __restrict__ ctl) {
+  __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
+  __shared__ double s_acc[kAccCopies * kMaxCamSlots * 9];
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  if ((int)blockIdx.x >= n_giant)
+    mf_matvec_block<false>(blockIdx.x - n_giant, s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, sp, X,
+                           Cinv, ptrec, x, slab);
+  else
+    mf_matvec_block<true>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, sp, X,
+                          Cinv, ptrec, x, slab);
 }
 
 // =============================================================================================
@@ -434,10 +455,121 @@ __device__ __forceinline__ void mf_cam_row(double* dst, const double* F, double 
   if (!ATOMIC) dst[63] = 0.0;
 }
 
+// residual and point block E = A R only (the point-side pass needs no F)
+__device__ __forceinline__ void mf_resid_E(const double* cd, double x0, double x1, double x2, double ox, double oy, double* E,
+                                           double& r0, double& r1) {
+  const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
+  const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
+  const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
+  const double f = cd[12], k1 = cd[13], k2 = cd[14];
+  const double iz = 1.0 / P2;
+  const double px = -P0 * iz, py = -P1 * iz;
+  const double n = px * px + py * py;
+  const double d = 1.0 + n * (k1 + k2 * n);
+  r0 = f * d * px - ox;
+  r1 = f * d * py - oy;
+  const double gg = k1 + 2.0 * k2 * n;
+  const double m00 = f * (d + 2.0 * gg * px * px), m01 = f * (2.0 * gg * px * py), m11 = f * (d + 2.0 * gg * py * py);
+  const double q0 = P0 * iz * iz, q1 = P1 * iz * iz;
+  double A[6];
+  A[0] = -m00 * iz; A[1] = -m01 * iz; A[2] = m00 * q0 + m01 * q1;
+  A[3] = -m01 * iz; A[4] = -m11 * iz; A[5] = m01 * q0 + m11 * q1;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    E[j] = A[0] * cd[j] + A[1] * cd[3 + j] + A[2] * cd[6 + j];
+    E[3 + j] = A[3] * cd[j] + A[4] * cd[3 + j] + A[5] * cd[6 + j];
+  }
+}
+
+// K2-mf, camera side: one wave per segment of at most kSegObs observations of ONE camera (camera-major copy of the
+// observation list).  Every lane keeps the 63 sums (upper triangle of F'F, F'v, F'r) of its observations in
+// registers; no atomics, no LDS until one cross-lane reduction per segment.  v = r - E z with the point's z from
+// the point-side pass (xz).  Row sg of slab gets the segment's sums; k_cam_reduce64 adds a camera's segments.
+constexpr int kSegObs = 1024;
+__global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __restrict__ seg /*{cam, first, count, -}*/,
+                                                    const int32_t* __restrict__ cmo_pt, const double2* __restrict__ cmo_xy,
+                                                    const double* __restrict__ ct, const double* __restrict__ cm,
+                                                    const double* __restrict__ xz, double* __restrict__ slab /*[n_seg][64]*/) {
+  __shared__ double s_red[4][64 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sg = blockIdx.x * 4 + wv;
+  if (sg >= n_seg) return;
+  const int4 S = seg[sg];
+  const int cam = __builtin_amdgcn_readfirstlane(S.x);
+  const int first = __builtin_amdgcn_readfirstlane(S.y), n = __builtin_amdgcn_readfirstlane(S.z);
+  double cd[kCamLds];
+  mf_stage_cam_init(cd, cam, ct, cm);
+  double acc[63];
+#pragma unroll
+  for (int k = 0; k < 63; ++k) acc[k] = 0.0;
+  // software pipeline with clamped (unconditional) prefetches: point index / measurement two ahead, xz one ahead
+  const int32_t* ptp = cmo_pt + first;
+  const double2* xyp = cmo_xy + first;
+  int i = lane;
+  int32_t pt_c = ptp[min(i, n - 1)];
+  double2 xy_c = xyp[min(i, n - 1)];
+  int32_t pt_n = ptp[min(i + 64, n - 1)];
+  double2 xy_n = xyp[min(i + 64, n - 1)];
+  double q_c[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) q_c[k] = xz[6 * (size_t)pt_c + k];
+  const int n_it = (n + 63) >> 6;
+  for (int it = 0; it < n_it; ++it, i += 64) {
+    double q_n[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q_n[k] = xz[6 * (size_t)pt_n + k];
+    const int32_t pt_n2 = ptp[min(i + 128, n - 1)];
+    const double2 xy_n2 = xyp[min(i + 128, n - 1)];
+    if (i < n) {
+      double F[18], E[6], r0, r1;
+      mf_blocks(cd, q_c[0], q_c[1], q_c[2], xy_c.x, xy_c.y, F, E, r0, r1);
+      const double v0 = r0 - (E[0] * q_c[3] + E[1] * q_c[4] + E[2] * q_c[5]);
+      const double v1 = r1 - (E[3] * q_c[3] + E[4] * q_c[4] + E[5] * q_c[5]);
+      int o = 0;
+#pragma unroll
+      for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int b = a; b < 9; ++b) {
+          acc[o] = fma(F[a], F[b], fma(F[9 + a], F[9 + b], acc[o]));
+          ++o;
+        }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        acc[45 + k] = fma(F[k], v0, fma(F[9 + k], v1, acc[45 + k]));
+        acc[54 + k] = fma(F[k], r0, fma(F[9 + k], r1, acc[54 + k]));
+      }
+    }
+    pt_n = pt_n2; xy_c = xy_n; xy_n = xy_n2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q_c[k] = q_n[k];
+  }
+  // cross-lane sums, nine components per round through the wave's LDS patch (LDS operations of one wave execute in
+  // order, so no barrier is needed between a round's writes and its reads)
+  double* sr = s_red[wv];
+  const int sub = lane / 9, k9 = lane % 9;
+  double* row = slab + (size_t)kK2W * sg;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sr[lane * 9 + k] = acc[9 * r + k];
+    __builtin_amdgcn_wave_barrier();
+    double a = 0.0;
+    if (lane < 63)
+      for (int l = sub; l < 64; l += 7) a += sr[l * 9 + k9];
+    double tot = a;
+#pragma unroll
+    for (int s2 = 1; s2 < 7; ++s2) tot += __shfl(a, k9 + 9 * s2, 64);
+    if (lane < 9) row[9 * r + lane] = tot;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) row[63] = 0.0;
+}
+
 // K2-mf: residual, cost, per-point Schur elimination and per-camera sums straight from the state.
 // Column scaling is NOT applied to F here (the raw camera sums are scaled by k_cam_reduce64); the point
 // scaling sp enters through mf_point_solve.  partial_cost[tile] = 0.5 sum r^2.
-template <bool GIANT>
+// ROWS = false: point side only (no F, no camera rows); X and z are also left in xz[p][6] for k_mf_camrows.
+template <bool GIANT, bool ROWS>
 __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                  const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                  const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
@@ -447,9 +579,10 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
                                                  const double* __restrict__ sp, double inv_radius, double dmin, double dmax,
                                                  double* __restrict__ Cinv, double* __restrict__ gp, double* __restrict__ dgp,
                                                  double* __restrict__ ptrec, double* __restrict__ slab /*[rows][64]*/,
+                                                 double* __restrict__ xz /*[npt][6]*/,
                                                  double* __restrict__ partial_cost, Ctl* __restrict__ ctl) {
   __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
-  __shared__ double s_acc[GIANT ? 1 : kMaxCamSlots * 63];
+  __shared__ double s_acc[(GIANT || !ROWS) ? 1 : kMaxCamSlots * 63];
   __shared__ double s4[4];
   const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
   const Tile t = tiles[tile_id];
@@ -458,7 +591,8 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
   double cost = 0.0;
   if (!GIANT) {
     if (tid < t.ncs) mf_stage_cam_init(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm);
-    for (int i = tid; i < t.ncs * 63; i += kChunk) s_acc[i] = 0.0;
+    if (ROWS)
+      for (int i = tid; i < t.ncs * 63; i += kChunk) s_acc[i] = 0.0;
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
     const int nwl = t.nslot / kWave;
@@ -471,7 +605,7 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
       const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
       const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
       const size_t p = (size_t)(gpt0 + pl);
-      double F[18], E[6], r0 = 0.0, r1 = 0.0, v[9];
+      double F[ROWS ? 18 : 1], E[6], r0 = 0.0, r1 = 0.0, v[9];
       double x0 = 0, x1 = 0, x2 = 0, s0 = 1, s1 = 1, s2 = 1;
 #pragma unroll
       for (int k = 0; k < 9; ++k) v[k] = 0.0;
@@ -482,7 +616,8 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         const double ox = oxy[chunk * (2 * kChunk) + l], oy = oxy[chunk * (2 * kChunk) + kChunk + l];
         double cd[kCamLds];
         mf_read_cam(cd, s_cam, cs);
-        mf_blocks(cd, x0, x1, x2, ox, oy, F, E, r0, r1);
+        if (ROWS) mf_blocks(cd, x0, x1, x2, ox, oy, F, E, r0, r1);
+        else mf_resid_E(cd, x0, x1, x2, ox, oy, E, r0, r1);
         cost += r0 * r0 + r1 * r1;
         v[0] = E[0] * E[0] + E[3] * E[3];
         v[1] = E[1] * E[0] + E[4] * E[3];
@@ -494,15 +629,9 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         v[7] = E[1] * r0 + E[4] * r1;
         v[8] = E[2] * r0 + E[5] * r1;
       }
-      for (int d = 1; d < maxrun; d <<= 1) {
-        const int src = (lane - d) << 2;
-        const bool in = pos >= d;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const double tk = lane_read(v[k], src);
-          v[k] += in ? tk : 0.0;
-        }
-      }
+      mf_seg_scan3(v[0], v[1], v[2], lane, pos, maxrun);
+      mf_seg_scan3(v[3], v[4], v[5], lane, pos, maxrun);
+      mf_seg_scan3(v[6], v[7], v[8], lane, pos, maxrun);
       const int last = (lane - pos + cnt - 1) << 2;
       double a[9];
 #pragma unroll
@@ -511,6 +640,10 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
       const bool ok = mf_point_solve(a, s0, s1, s2, inv_radius, dmin, dmax, ci, g, dg, W, z);
       if (valid) {
         if (pos == 0) {
+          if (!ROWS) {
+            double* q6 = xz + 6 * p;
+            q6[0] = x0; q6[1] = x1; q6[2] = x2; q6[3] = z[0]; q6[4] = z[1]; q6[5] = z[2];
+          }
           if (!ok) ctl->fail = 1;
 #pragma unroll
           for (int k = 0; k < 6; ++k) Cinv[6 * p + k] = ci[k];
@@ -523,15 +656,19 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
 #pragma unroll
           for (int k = 0; k < 3; ++k) rp[9 + k] = z[k];
         }
-        const double v0 = r0 - (E[0] * z[0] + E[1] * z[1] + E[2] * z[2]);
-        const double v1 = r1 - (E[3] * z[0] + E[4] * z[1] + E[5] * z[2]);
-        mf_cam_row<true>(s_acc + 63 * cs, F, v0, v1, r0, r1);
+        if (ROWS) {
+          const double v0 = r0 - (E[0] * z[0] + E[1] * z[1] + E[2] * z[2]);
+          const double v1 = r1 - (E[3] * z[0] + E[4] * z[1] + E[5] * z[2]);
+          mf_cam_row<true>(s_acc + 63 * cs, F, v0, v1, r0, r1);
+        }
       }
     }
-    __syncthreads();
-    for (int i = tid; i < t.ncs * kK2W; i += kChunk) {
-      const int s = i >> 6, k = i & 63;
-      slab[(size_t)kK2W * slab_row[t.cam0 + s] + k] = (k < 63) ? s_acc[s * 63 + k] : 0.0;
+    if (ROWS) {
+      __syncthreads();
+      for (int i = tid; i < t.ncs * kK2W; i += kChunk) {
+        const int s = i >> 6, k = i & 63;
+        slab[(size_t)kK2W * slab_row[t.cam0 + s] + k] = (k < 63) ? s_acc[s * 63 + k] : 0.0;
+      }
     }
   } else {
     for (int gi = 0; gi < t.ngrp; ++gi) {
@@ -574,8 +711,12 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         for (int k = 0; k < 6; ++k) rp[3 + k] = W[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) rp[9 + k] = z[k];
+        if (!ROWS) {
+          double* q6 = xz + 6 * p;
+          q6[0] = x0; q6[1] = x1; q6[2] = x2; q6[3] = z[0]; q6[4] = z[1]; q6[5] = z[2];
+        }
       }
-      for (int ch = 0; ch < G.nchunk; ++ch) {
+      for (int ch = 0; ROWS && ch < G.nchunk; ++ch) {
         const size_t chunk = (size_t)(G.chunk0 + ch);
         const size_t slot = chunk * kChunk + tid;
         if (idx[slot] < 0) continue;

@@ -286,3 +286,14 @@ def test_rccl_path_single_rank(medium):
     assert rel(a["Sv"], b["Sv"]) <= 1e-12 and rel(a["y_cam"], b["y_cam"]) <= 1e-9
     assert [r["linear_solver_iterations"] for r in ia[:5]] == [r["linear_solver_iterations"] for r in ib[:5]]
     assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
+
+
+def test_k2_one_pass_matches_two_pass(medium):
+    """K2-mf camera rows by LDS atomics in one pass (MIBA_K2_ONEPASS=1) against the default two-pass form
+    (point side over wavelets, camera side over the camera-major observation copy)."""
+    pr, cams0, pts0 = medium
+    a, ia, sa = _solve_with_env(pr, cams0, pts0, {})
+    b, ib, sb = _solve_with_env(pr, cams0, pts0, {"MIBA_K2_ONEPASS": "1"})
+    assert rel(a["rhs"], b["rhs"]) <= 1e-11 and rel(a["Sv"], b["Sv"]) <= 1e-11
+    assert a["n_cg"] == b["n_cg"]
+    assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
