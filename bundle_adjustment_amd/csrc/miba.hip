@@ -71,7 +71,7 @@ struct miba_handle_s {
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
   // camera-major copy of the local observations (K2-mf camera side): segments of one camera each
   int4* d_seg = nullptr; int32_t* d_cmo_pt = nullptr; double2* d_cmo_xy = nullptr; int32_t* d_cam_seg_off = nullptr;
-  double *d_slabB = nullptr, *d_xz = nullptr;
+  double* d_slabB = nullptr;
   int32_t n_seg = 0;
   bool k2_onepass = false;                        // MIBA_K2_ONEPASS=1: K2-mf with LDS-atomic camera rows in one pass
   int32_t n_giant = 0;
@@ -254,13 +254,13 @@ constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 +
 // K2 + camera reductions + camera blocks; fills Cinv, gp, Minv, Dc2, rhs and the gradient norms
 // K2-mf over all tiles of this shard (camera tables of the current state must be in d_ct / d_cm):
 // per-point blocks, raw camera slab rows, cost -> d_sum[S_COST] (all-reduced)
-int mf_init_launch(miba_handle h, double inv_r, const miba_options* o) {
+int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want_diag) {
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
 #define MIBA_INIT_ARGS(list)                                                                                              \
   h->d_tiles, list, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm,   \
-      h->d_X, h->d_sp, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp, h->d_dgp, h->d_ptrec,            \
-      h->d_slab64, h->d_xz, h->d_part_tile, h->d_ctl
+      h->d_X, h->d_sp, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_gp, want_diag ? h->d_dgp : (double*)nullptr,    \
+      h->d_ptrec, h->d_slab64, h->d_part_tile, h->d_ctl
     if (h->k2_onepass) {
       hipLaunchKernelGGL((k_mf_init<false, true>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
                          MIBA_INIT_ARGS((const int32_t*)nullptr));
@@ -274,12 +274,14 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o) {
         hipLaunchKernelGGL((k_mf_init<true, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
       if (h->n_seg)
         hipLaunchKernelGGL(k_mf_camrows, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
-                           h->d_ct, h->d_cm, h->d_xz, h->d_slabB);
+                           h->d_ct, h->d_cm, h->d_ptrec, h->d_slabB);
     }
 #undef MIBA_INIT_ARGS
   }
   HIPCHK(h, hipGetLastError());
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 0, 0, h->d_sum + S_COST);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 1, 1, h->d_max + S_GMAX_P);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 2, 0, h->d_sum + S_G2_P);
   HIPCHK(h, hipGetLastError());
   return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
 }
@@ -298,7 +300,7 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   HIPCHK(h, hipMemsetAsync(&h->d_ctl->fail, 0, sizeof(int32_t), h->st));
   int rc;
   if (h->use_mf) {
-    rc = mf_init_launch(h, inv_r, o);
+    rc = mf_init_launch(h, inv_r, o, false);
     if (rc) return rc;
   } else if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
@@ -318,12 +320,14 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 0, 1, h->d_max + S_GMAX_C);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 1, 0, h->d_sum + S_G2_C);
   HIPCHK(h, hipGetLastError());
-  // point gradient norms (local points), then all-reduce
-  const int nbp = 240;
-  double* pp = h->d_part_small + 2 * (size_t)nb;
-  hipLaunchKernelGGL(k_pt_gradnorm, dim3(nbp), dim3(256), 0, h->st, h->n_pt, h->d_gp, h->d_sp, pp);
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 0, 1, h->d_max + S_GMAX_P);
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 1, 0, h->d_sum + S_G2_P);
+  // point gradient norms (local points; the matrix-free K2 has already left them), then all-reduce
+  if (!h->use_mf) {
+    const int nbp = 240;
+    double* pp = h->d_part_small + 2 * (size_t)nb;
+    hipLaunchKernelGGL(k_pt_gradnorm, dim3(nbp), dim3(256), 0, h->st, h->n_pt, h->d_gp, h->d_sp, pp);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 0, 1, h->d_max + S_GMAX_P);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 1, 0, h->d_sum + S_G2_P);
+  }
   HIPCHK(h, hipGetLastError());
   rc = allreduce(h, h->d_sum + S_G2_P, 1, ncclSum);
   if (rc) return rc;
@@ -338,7 +342,7 @@ int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* pa
       Timed t(h, MIBA_K_SCHUR_MATVEC);
       hipLaunchKernelGGL(k_mf_matvec, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles,
                          h->d_giant, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm,
-                         h->d_sc, h->d_sp, h->d_X, h->d_Cinv, h->d_ptrec, x, h->d_slab9, ctl);
+                         h->d_sc, h->d_X, h->d_ptrec, x, h->d_slab9, ctl);
     }
     hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
                        h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->comm ? (double*)nullptr : part_xy,
@@ -380,7 +384,7 @@ int unit_scale(miba_handle h);
 int make_scale_mf(miba_handle h, const miba_options* o) {
   int rc = unit_scale(h);
   if (rc) return rc;
-  rc = mf_init_launch(h, 1.0, o);
+  rc = mf_init_launch(h, 1.0, o, true);
   if (rc) return rc;
   rc = cam_reduce64(h, nullptr);
   if (rc) return rc;
@@ -824,7 +828,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   h->n_giant = (int32_t)giant.size();
   ALLOC(h->d_giant, giant.size());
   ALLOC(h->d_seg, segv.size()); ALLOC(h->d_cmo_pt, cmo_pt.size()); ALLOC(h->d_cmo_xy, cmo_xy.size());
-  ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_slabB, (size_t)kK2W * segv.size()); ALLOC(h->d_xz, 6 * np);
+  ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_slabB, (size_t)kK2W * segv.size());
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ til
                                                     double* __restrict__ dgp /*[npt][3] diag E'E*/,
                                                     double* __restrict__ slab /*[nrows][64]*/, Ctl* __restrict__ ctl,
                                                     const double* __restrict__ X, const double* __restrict__ sp,
-                                                    double* __restrict__ ptrec /*[npt][kPtRec]: X, sp C^-1 sp, sp C^-1 g*/) {
+                                                    double* __restrict__ ptrec /*[npt][kPtRec]: X, sp C^-1 g, sp C^-1 sp*/) {
   extern __shared__ double lds[];
   double* s_acc = lds;                              // [kMaxCamSlots][63]  (stride 63: odd => fewer bank conflicts)
   double* s_stage = lds + kMaxCamSlots * 63;        // [256][9]
@@ -362,15 +362,15 @@ __global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ til
           double* rp = ptrec + (size_t)kPtRec * (size_t)p;
           const double s0 = sp[3 * (size_t)p], s1 = sp[3 * (size_t)p + 1], s2 = sp[3 * (size_t)p + 2];
           rp[0] = X[3 * (size_t)p]; rp[1] = X[3 * (size_t)p + 1]; rp[2] = X[3 * (size_t)p + 2];
-          rp[3] = s0 * ci[0] * s0; rp[4] = s1 * ci[1] * s0; rp[5] = s1 * ci[2] * s1;
-          rp[6] = s2 * ci[3] * s0; rp[7] = s2 * ci[4] * s1; rp[8] = s2 * ci[5] * s2;
+          rp[6] = s0 * ci[0] * s0; rp[7] = s1 * ci[1] * s0; rp[8] = s1 * ci[2] * s1;
+          rp[9] = s2 * ci[3] * s0; rp[10] = s2 * ci[4] * s1; rp[11] = s2 * ci[5] * s2;
         }
         gp[3 * (size_t)p] = a[6]; gp[3 * (size_t)p + 1] = a[7]; gp[3 * (size_t)p + 2] = a[8];
         s_y[tid * 3 + 0] = ci[0] * a[6] + ci[1] * a[7] + ci[3] * a[8];
         s_y[tid * 3 + 1] = ci[1] * a[6] + ci[2] * a[7] + ci[4] * a[8];
         s_y[tid * 3 + 2] = ci[3] * a[6] + ci[4] * a[7] + ci[5] * a[8];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ptrec[(size_t)kPtRec * (size_t)p + 9 + k] = sp[3 * (size_t)p + k] * s_y[tid * 3 + k];
+        for (int k = 0; k < 3; ++k) ptrec[(size_t)kPtRec * (size_t)p + 3 + k] = sp[3 * (size_t)p + k] * s_y[tid * 3 + k];
       }
       __syncthreads();
       if (valid) {

@@ -175,12 +175,14 @@ __device__ __forceinline__ void mf_seg_scan3(double& v0, double& v1, double& v2,
   }
 }
 
-// gather of the first 9 doubles of a point record (lanes of one point read the same 72 bytes)
+// gather of X and W of a point record (lanes of one point read the same bytes)
 __device__ __forceinline__ void mf_load_rec9(double* rec, const double* __restrict__ ptrec, int32_t w, int chunk_pt0) {
   const int pl = (w >= 0) ? (w & 0xFF) : 0;   // pad lanes read the chunk's first point: no branch, finite data
   const double* rp = ptrec + (size_t)kPtRec * (size_t)(chunk_pt0 + pl);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) rec[k] = rp[k];
+  for (int k = 0; k < 3; ++k) rec[k] = rp[k];       // X
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rec[3 + k] = rp[6 + k];   // W
 }
 
 // Wavelet loop of one wave over its tile (wavelets wv, wv+4, ...), software-pipelined: the index word of
@@ -256,8 +258,7 @@ __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, d
                                                    const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
                                                    const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
                                                    const double* __restrict__ ct, const double* __restrict__ cm,
-                                                   const double* __restrict__ sc, const double* __restrict__ sp,
-                                                   const double* __restrict__ X, const double* __restrict__ Cinv,
+                                                   const double* __restrict__ sc, const double* __restrict__ X,
                                                    const double* __restrict__ ptrec /*[npt][kPtRec]*/,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/) {
   const Tile t = tiles[tile_index];
@@ -302,12 +303,10 @@ __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, d
         }
         a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
       }
-      const double* ci = Cinv + 6 * (size_t)p;
-      const double* s = sp + 3 * (size_t)p;
-      a0 *= s[0]; a1 *= s[1]; a2 *= s[2];
-      const double y0 = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2) * s[0];
-      const double y1 = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2) * s[1];
-      const double y2 = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2) * s[2];
+      const double* W = ptrec + (size_t)kPtRec * (size_t)p + 6;   // diag(sp) C^-1 diag(sp)
+      const double y0 = -(W[0] * a0 + W[1] * a1 + W[3] * a2);
+      const double y1 = -(W[1] * a0 + W[2] * a1 + W[4] * a2);
+      const double y2 = -(W[3] * a0 + W[4] * a1 + W[5] * a2);
       for (int ch = 0; ch < G.nchunk; ++ch) {
         const size_t slot = (size_t)(G.chunk0 + ch) * kChunk + tid;
         if (idx[slot] < 0) continue;
@@ -337,8 +336,7 @@ __global__ __launch_bounds__(256) void k_mf_matvec(int n_giant, const Tile* __re
                                                    const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
                                                    const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
                                                    const double* __restrict__ ct, const double* __restrict__ cm,
-                                                   const double* __restrict__ sc, const double* __restrict__ sp,
-                                                   const double* __restrict__ X, const double* __restrict__ Cinv,
+                                                   const double* __restrict__ sc, const double* __restrict__ X,
                                                    const double* __restrict__ ptrec /*[npt][kPtRec]*/,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
                                                    const Ctl* __restrict__ ctl) {
@@ -347,11 +345,11 @@ __global__ __launch_bounds__(256) void k_mf_matvec(int n_giant, const Tile* __re
   __shared__ double s4[4];
   if (ctl->done) return;
   if ((int)blockIdx.x >= n_giant)
-    mf_matvec_block<false>(blockIdx.x - n_giant, s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, sp, X,
-                           Cinv, ptrec, x, slab);
+    mf_matvec_block<false>(blockIdx.x - n_giant, s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X, ptrec,
+                           x, slab);
   else
-    mf_matvec_block<true>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, sp, X,
-                          Cinv, ptrec, x, slab);
+    mf_matvec_block<true>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X, ptrec,
+                          x, slab);
 }
 
 // =============================================================================================
@@ -433,6 +431,12 @@ __device__ __forceinline__ bool mf_point_solve(const double* a, double s0, doubl
   return ok;
 }
 
+// gradient norms of the unscaled problem for one point: g / sp is E'r of the unscaled blocks, a[6..8]
+__device__ __forceinline__ void mf_grad_norms(const double* a, double& gmax, double& g2) {
+  gmax = fmax(gmax, fmax(fabs(a[6]), fmax(fabs(a[7]), fabs(a[8]))));
+  g2 += a[6] * a[6] + a[7] * a[7] + a[8] * a[8];
+}
+
 // camera-row contribution of one observation: upper triangle of F'F (45), F'v (9), F'r (9); ATOMIC: LDS accumulate
 template <bool ATOMIC>
 __device__ __forceinline__ void mf_cam_row(double* dst, const double* F, double v0, double v1, double r0, double r1) {
@@ -484,12 +488,12 @@ __device__ __forceinline__ void mf_resid_E(const double* cd, double x0, double x
 // K2-mf, camera side: one wave per segment of at most kSegObs observations of ONE camera (camera-major copy of the
 // observation list).  Every lane keeps the 63 sums (upper triangle of F'F, F'v, F'r) of its observations in
 // registers; no atomics, no LDS until one cross-lane reduction per segment.  v = r - E z with the point's z from
-// the point-side pass (xz).  Row sg of slab gets the segment's sums; k_cam_reduce64 adds a camera's segments.
+// the point-side pass (point record).  Row sg of slab gets the segment's sums; k_cam_reduce64 adds a camera's segments.
 constexpr int kSegObs = 1024;
 __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __restrict__ seg /*{cam, first, count, -}*/,
                                                     const int32_t* __restrict__ cmo_pt, const double2* __restrict__ cmo_xy,
                                                     const double* __restrict__ ct, const double* __restrict__ cm,
-                                                    const double* __restrict__ xz, double* __restrict__ slab /*[n_seg][64]*/) {
+                                                    const double* __restrict__ ptrec, double* __restrict__ slab /*[n_seg][64]*/) {
   __shared__ double s_red[4][64 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int sg = blockIdx.x * 4 + wv;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __res
   double acc[63];
 #pragma unroll
   for (int k = 0; k < 63; ++k) acc[k] = 0.0;
-  // software pipeline with clamped (unconditional) prefetches: point index / measurement two ahead, xz one ahead
+  // software pipeline with clamped (unconditional) prefetches: point index / measurement two ahead, point record one ahead
   const int32_t* ptp = cmo_pt + first;
   const double2* xyp = cmo_xy + first;
   int i = lane;
@@ -512,12 +516,12 @@ __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __res
   double2 xy_n = xyp[min(i + 64, n - 1)];
   double q_c[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) q_c[k] = xz[6 * (size_t)pt_c + k];
+  for (int k = 0; k < 6; ++k) q_c[k] = ptrec[(size_t)kPtRec * (size_t)pt_c + k];   // X, z
   const int n_it = (n + 63) >> 6;
   for (int it = 0; it < n_it; ++it, i += 64) {
     double q_n[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) q_n[k] = xz[6 * (size_t)pt_n + k];
+    for (int k = 0; k < 6; ++k) q_n[k] = ptrec[(size_t)kPtRec * (size_t)pt_n + k];
     const int32_t pt_n2 = ptp[min(i + 128, n - 1)];
     const double2 xy_n2 = xyp[min(i + 128, n - 1)];
     if (i < n) {
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __res
 // K2-mf: residual, cost, per-point Schur elimination and per-camera sums straight from the state.
 // Column scaling is NOT applied to F here (the raw camera sums are scaled by k_cam_reduce64); the point
 // scaling sp enters through mf_point_solve.  partial_cost[tile] = 0.5 sum r^2.
-// ROWS = false: point side only (no F, no camera rows); X and z are also left in xz[p][6] for k_mf_camrows.
+// ROWS = false: point side only (no F, no camera rows); k_mf_camrows takes X and z from the point records.
 template <bool GIANT, bool ROWS>
 __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                  const Group* __restrict__ grps, const int32_t* __restrict__ idx,
@@ -577,10 +581,10 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
                                                  const double* __restrict__ oxy, const double* __restrict__ ct,
                                                  const double* __restrict__ cm, const double* __restrict__ X,
                                                  const double* __restrict__ sp, double inv_radius, double dmin, double dmax,
-                                                 double* __restrict__ Cinv, double* __restrict__ gp, double* __restrict__ dgp,
+                                                 double* __restrict__ gp, double* __restrict__ dgp /*diag E'E, or null*/,
                                                  double* __restrict__ ptrec, double* __restrict__ slab /*[rows][64]*/,
-                                                 double* __restrict__ xz /*[npt][6]*/,
-                                                 double* __restrict__ partial_cost, Ctl* __restrict__ ctl) {
+                                                 double* __restrict__ partial /*[tile][4]: cost, max |g_p|, |g_p|^2*/,
+                                                 Ctl* __restrict__ ctl) {
   __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
   __shared__ double s_acc[(GIANT || !ROWS) ? 1 : kMaxCamSlots * 63];
   __shared__ double s4[4];
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
   const Tile t = tiles[tile_id];
   if (!GIANT && t.giant) return;
   const int tid = threadIdx.x;
-  double cost = 0.0;
+  double cost = 0.0, gmax = 0.0, g2 = 0.0;   // gradient norms of the unscaled problem: g / sp
   if (!GIANT) {
     if (tid < t.ncs) mf_stage_cam_init(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm);
     if (ROWS)
@@ -640,21 +644,21 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
       const bool ok = mf_point_solve(a, s0, s1, s2, inv_radius, dmin, dmax, ci, g, dg, W, z);
       if (valid) {
         if (pos == 0) {
-          if (!ROWS) {
-            double* q6 = xz + 6 * p;
-            q6[0] = x0; q6[1] = x1; q6[2] = x2; q6[3] = z[0]; q6[4] = z[1]; q6[5] = z[2];
-          }
+
           if (!ok) ctl->fail = 1;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) Cinv[6 * p + k] = ci[k];
+          for (int k = 0; k < 3; ++k) gp[3 * p + k] = g[k];
+          if (dgp) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) { gp[3 * p + k] = g[k]; dgp[3 * p + k] = dg[k]; }
+            for (int k = 0; k < 3; ++k) dgp[3 * p + k] = dg[k];
+          }
+          mf_grad_norms(a, gmax, g2);
           double* rp = ptrec + (size_t)kPtRec * p;
           rp[0] = x0; rp[1] = x1; rp[2] = x2;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) rp[3 + k] = W[k];
+          for (int k = 0; k < 6; ++k) rp[6 + k] = W[k];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) rp[9 + k] = z[k];
+          for (int k = 0; k < 3; ++k) rp[3 + k] = z[k];
         }
         if (ROWS) {
           const double v0 = r0 - (E[0] * z[0] + E[1] * z[1] + E[2] * z[2]);
@@ -702,19 +706,18 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
       if (tid == 0) {
         if (!ok) ctl->fail = 1;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Cinv[6 * p + k] = ci[k];
+        for (int k = 0; k < 3; ++k) gp[3 * p + k] = g[k];
+        if (dgp) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { gp[3 * p + k] = g[k]; dgp[3 * p + k] = dg[k]; }
+          for (int k = 0; k < 3; ++k) dgp[3 * p + k] = dg[k];
+        }
+        mf_grad_norms(a, gmax, g2);
         double* rp = ptrec + (size_t)kPtRec * p;
         rp[0] = x0; rp[1] = x1; rp[2] = x2;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) rp[3 + k] = W[k];
+        for (int k = 0; k < 6; ++k) rp[6 + k] = W[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rp[9 + k] = z[k];
-        if (!ROWS) {
-          double* q6 = xz + 6 * p;
-          q6[0] = x0; q6[1] = x1; q6[2] = x2; q6[3] = z[0]; q6[4] = z[1]; q6[5] = z[2];
-        }
+        for (int k = 0; k < 3; ++k) rp[3 + k] = z[k];
       }
       for (int ch = 0; ROWS && ch < G.nchunk; ++ch) {
         const size_t chunk = (size_t)(G.chunk0 + ch);
@@ -730,7 +733,14 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
     }
   }
   const double tot = block_sum(cost, s4);
-  if (tid == 0) partial_cost[tile_id] = 0.5 * tot;
+  const double bm = block_max(gmax, s4);
+  const double b2 = block_sum(g2, s4);
+  if (tid == 0) {
+    partial[4 * (size_t)tile_id + 0] = 0.5 * tot;
+    partial[4 * (size_t)tile_id + 1] = bm;
+    partial[4 * (size_t)tile_id + 2] = b2;
+    partial[4 * (size_t)tile_id + 3] = 0.0;
+  }
 }
 
 // K4-mf: back-substitution  z_p = sp.(C^-1 (g_p - sum E_s' F_s y_c)) = zg - W sum E'u, candidate points
@@ -795,9 +805,9 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
       const int last = (lane - pos + cnt - 1) << 2;
       const double a0 = lane_read(v0, last), a1 = lane_read(v1, last), a2 = lane_read(v2, last);
       if (valid) {
-        const double z0 = rec[9] - (rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
-        const double z1 = rec[10] - (rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
-        const double z2 = rec[11] - (rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
+        const double z0 = rec[3] - (rec[6] * a0 + rec[7] * a1 + rec[9] * a2);
+        const double z1 = rec[4] - (rec[7] * a0 + rec[8] * a1 + rec[10] * a2);
+        const double z2 = rec[5] - (rec[9] * a0 + rec[10] * a1 + rec[11] * a2);
         const double m0 = u0 + geo.E[0] * z0 + geo.E[1] * z1 + geo.E[2] * z2;
         const double m1 = u1 + geo.E[3] * z0 + geo.E[4] * z1 + geo.E[5] * z2;
         mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
@@ -833,9 +843,9 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         }
         a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
       }
-      const double z0 = rec[9] - (rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
-      const double z1 = rec[10] - (rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
-      const double z2 = rec[11] - (rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
+      const double z0 = rec[3] - (rec[6] * a0 + rec[7] * a1 + rec[9] * a2);
+      const double z1 = rec[4] - (rec[7] * a0 + rec[8] * a1 + rec[10] * a2);
+      const double z2 = rec[5] - (rec[9] * a0 + rec[10] * a1 + rec[11] * a2);
       if (tid == 0) {
         yp[3 * p] = z0 / sp[3 * p]; yp[3 * p + 1] = z1 / sp[3 * p + 1]; yp[3 * p + 2] = z2 / sp[3 * p + 2];
         const double c0 = rec[0] - z0, c1 = rec[1] - z1, c2 = rec[2] - z2;

@@ -23,7 +23,7 @@ constexpr int kWave = 64;          // a point never straddles a 64-slot wavelet 
 constexpr int kMaxCamSlots = 64;   // distinct cameras per (non-giant) tile: LDS accumulator rows
 constexpr int kMaxChunksPerTile = 8;   // default; MIBA_TILE_CHUNKS overrides (1..16)
 constexpr int kJComp = 26;         // doubles stored per observation: F 18, E 6, r 2
-constexpr int kPtRec = 12;        // per-point record: X 0..2 | W = diag(sp) C^-1 diag(sp) 3..8 | zg = sp.(C^-1 g) 9..11
+constexpr int kPtRec = 12;        // per-point record: X 0..2 | z = sp.(C^-1 g) 3..5 | W = diag(sp) C^-1 diag(sp) 6..11
 constexpr int kCamTabStride = 48;  // per-camera table row (R 9, t 3, f k1 k2, pad, dR 27, pad)
 
 struct Tile {   // 32 bytes
