@@ -238,7 +238,11 @@ int eval_cost(miba_handle h, const double* cam, const double* X) {
   // candidate state: its camera table must not disturb the table of the current state (K3-mf reads it)
   int rc = launch_cam_tables(h, cam, true);
   if (rc) return rc;
-  if (h->n_tiles) {
+  if (h->n_tiles && h->use_mf) {
+    Timed t(h, MIBA_K_EVAL_COST);
+    hipLaunchKernelGGL(k_mf_cost, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles,
+                       h->d_giant, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct_cand, X, h->d_part_tile);
+  } else if (h->n_tiles) {
     Timed t(h, MIBA_K_EVAL_COST);
     hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
                        h->d_ocam, h->d_oxy, h->d_ct_cand, X, nullptr, nullptr, nullptr, h->d_part_tile);

@@ -883,6 +883,81 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
   }
 }
 
+// K1'-mf: cost 0.5 sum |r|^2 of a (candidate) state.  Same tile walk as the other matrix-free kernels: the tile's
+// cameras (R, t, f, k1, k2) are staged in LDS, every lane gathers its point and reads its measurement.
+// The first n_giant blocks take the giant tiles of tile_list, block n_giant + i takes tile i.
+constexpr int kCamCost = 16;   // 15 doubles used: 8 x ds_read_b128
+__global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                 const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                 const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
+                                                 const int32_t* __restrict__ tile_cams, const double* __restrict__ oxy,
+                                                 const double* __restrict__ ct, const double* __restrict__ X,
+                                                 double* __restrict__ partial_cost) {
+  __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamCost];
+  __shared__ double s4[4];
+  const bool giant = (int)blockIdx.x < n_giant;
+  const int tile_id = giant ? tile_list[blockIdx.x] : (int)blockIdx.x - n_giant;
+  const Tile t = tiles[tile_id];
+  if (!giant && t.giant) return;
+  const int tid = threadIdx.x;
+  double cost = 0.0;
+  if (!giant) {
+    if (tid < t.ncs) {
+      const double* T = ct + (size_t)kCamTabStride * tile_cams[t.cam0 + tid];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) s_cam[kCamCost * tid + k] = T[k];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int nwl = t.nslot / kWave;
+    for (int q = wv; q < nwl; q += 4) {
+      const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
+      const int32_t w = idx[slot];
+      if (w < 0) continue;
+      const size_t p = (size_t)(wl[(t.slot0 >> 6) + q].x + (w & 0xFF));
+      const double x0 = X[3 * p], x1 = X[3 * p + 1], x2 = X[3 * p + 2];
+      const size_t chunk = slot / kChunk, l = slot % kChunk;
+      const double ox = oxy[chunk * (2 * kChunk) + l], oy = oxy[chunk * (2 * kChunk) + kChunk + l];
+      const double2* c2 = reinterpret_cast<const double2*>(s_cam) + (kCamCost / 2) * ((w >> 8) & 0xFF);
+      double cd[kCamCost];
+#pragma unroll
+      for (int k = 0; k < kCamCost / 2; ++k) { const double2 v = c2[k]; cd[2 * k] = v.x; cd[2 * k + 1] = v.y; }
+      const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
+      const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
+      const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
+      const double iz = 1.0 / P2;
+      const double px = -P0 * iz, py = -P1 * iz;
+      const double n = px * px + py * py;
+      const double d = 1.0 + n * (cd[13] + cd[14] * n);
+      const double r0 = cd[12] * d * px - ox, r1 = cd[12] * d * py - oy;
+      cost += r0 * r0 + r1 * r1;
+    }
+  } else {
+    for (int gi = 0; gi < t.ngrp; ++gi) {
+      const Group G = grps[t.grp0 + gi];
+      const size_t p = (size_t)G.pt0;
+      const double x0 = X[3 * p], x1 = X[3 * p + 1], x2 = X[3 * p + 2];
+      for (int ch = 0; ch < G.nchunk; ++ch) {
+        const size_t chunk = (size_t)(G.chunk0 + ch);
+        const size_t slot = chunk * kChunk + tid;
+        if (idx[slot] < 0) continue;
+        const double* cd = ct + (size_t)kCamTabStride * ocam[slot];
+        const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
+        const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
+        const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
+        const double iz = 1.0 / P2;
+        const double px = -P0 * iz, py = -P1 * iz;
+        const double n = px * px + py * py;
+        const double d = 1.0 + n * (cd[13] + cd[14] * n);
+        const double r0 = cd[12] * d * px - oxy[chunk * (2 * kChunk) + tid], r1 = cd[12] * d * py - oxy[chunk * (2 * kChunk) + kChunk + tid];
+        cost += r0 * r0 + r1 * r1;
+      }
+    }
+  }
+  const double tot = block_sum(cost, s4);
+  if (tid == 0) partial_cost[tile_id] = 0.5 * tot;
+}
+
 // Jacobi scale from the raw (unit-scale) camera sums: sc = 1 / (1 + sqrt(diag F'F))
 __global__ void k_scale_from_acc(int n_cam, const double* __restrict__ acc, double* __restrict__ sc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
