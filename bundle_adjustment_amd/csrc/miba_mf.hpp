@@ -796,12 +796,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         r0 = geo.f * geo.d * geo.px - oxy[chunk * (2 * kChunk) + l];
         r1 = geo.f * geo.d * geo.py - oxy[chunk * (2 * kChunk) + kChunk + l];
       }
-      for (int d = 1; d < maxrun; d <<= 1) {
-        const int src = (lane - d) << 2;
-        const double t0 = lane_read(v0, src), t1 = lane_read(v1, src), t2 = lane_read(v2, src);
-        const bool in = pos >= d;
-        v0 += in ? t0 : 0.0; v1 += in ? t1 : 0.0; v2 += in ? t2 : 0.0;
-      }
+      mf_seg_scan3(v0, v1, v2, lane, pos, maxrun);
       const int last = (lane - pos + cnt - 1) << 2;
       const double a0 = lane_read(v0, last), a1 = lane_read(v1, last), a2 = lane_read(v2, last);
       if (valid) {
