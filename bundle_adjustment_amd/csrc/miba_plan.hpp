@@ -3,9 +3,10 @@
 // Replaces the host loop of BundleAdjustment::createProblem
 // (/root/reference/src/BundleAdjustment.cpp:44-86): the same observation filter (:49-60), but
 // instead of one heap-allocated cost function per observation (BAConstraint::create,
-// src/BAConstraint.cpp:82-86) the observations are sorted by point, cut into 256-slot chunks
-// that never split a point, and grouped into tiles whose distinct cameras fit an LDS
-// accumulator.  Pure C++ (no HIP): used by miba_set_problem and miba_plan_shards.
+// src/BAConstraint.cpp:82-86) the observations are grouped by point and cut into tiles (whole
+// points, at most kMaxCamSlots distinct cameras); inside a tile the points are packed into 64-slot
+// wavelets that never split a point, four wavelets to a 256-slot chunk.  Pure C++ (no HIP): used by
+// miba_set_problem and miba_plan_shards.
 #pragma once
 
 #include <algorithm>
