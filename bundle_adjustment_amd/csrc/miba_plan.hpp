@@ -116,7 +116,6 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   // --- tiling, phase 1: cut the point sequence into tiles.  A tile holds whole points, at most kMaxCamSlots
   // distinct cameras and about max_chunks chunks of observations; a giant point (more observations than a
   // wavefront) is a tile of its own.
-  if ((P.n_valid + (int64_t)n_act * kChunk) >= (int64_t)INT32_MAX) return -6;  // slots are int32
   struct Span { int32_t s0, s1, giant; };
   std::vector<Span> spans;
   {
@@ -263,7 +262,9 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     }
     T.nslot = (int32_t)(slots - T.slot0);
     P.tiles.push_back(T);
+    if (slots >= (int64_t)INT32_MAX - kChunk) return -6;
   }
+  if (slots >= (int64_t)INT32_MAX - kChunk) return -6;   // slot indices are int32 on the device
   P.pt_orig.swap(new_orig);
   P.n_slots = slots;
   P.wl_npt.assign((size_t)(slots / kWave) + 1, 0);
