@@ -72,6 +72,7 @@ struct miba_handle_s {
   // camera-major copy of the local observations (K2-mf camera side): segments of one camera each
   int4* d_seg = nullptr; int32_t* d_cmo_pt = nullptr; double2* d_cmo_xy = nullptr; int32_t* d_cam_seg_off = nullptr;
   double* d_slabB = nullptr;
+  double* d_cfree = nullptr;                      // [n_cam][9] 1 = free, 0 = entry of a constant parameter block
   int32_t n_seg = 0;
   bool k2_onepass = false;                        // MIBA_K2_ONEPASS=1: K2-mf with LDS-atomic camera rows in one pass
   int32_t n_giant = 0;
@@ -365,6 +366,13 @@ int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* pa
   return allreduce(h, y, 9 * (size_t)h->n_cam, ncclSum);
 }
 
+// constant parameter blocks: a zero scale removes the column from every kernel (F_s = F diag(sc))
+int apply_const_mask(miba_handle h) {
+  hipLaunchKernelGGL(k_mul, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_cfree, h->d_sc);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
 // Jacobi scale from the UNSCALED Jacobian currently in d_J
 int make_scale(miba_handle h) {
   if (h->n_tiles)
@@ -378,7 +386,7 @@ int make_scale(miba_handle h) {
   hipLaunchKernelGGL(k_make_scale, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_sc, h->d_sc);
   hipLaunchKernelGGL(k_make_scale, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_sp, h->d_sp);
   HIPCHK(h, hipGetLastError());
-  return MIBA_OK;
+  return apply_const_mask(h);
 }
 
 int unit_scale(miba_handle h);
@@ -397,7 +405,7 @@ int make_scale_mf(miba_handle h, const miba_options* o) {
   hipLaunchKernelGGL(k_scale_from_acc, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, h->d_camacc, h->d_sc);
   hipLaunchKernelGGL(k_make_scale, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_dgp, h->d_sp);
   HIPCHK(h, hipGetLastError());
-  return MIBA_OK;
+  return apply_const_mask(h);
 }
 
 int unit_scale(miba_handle h) {
@@ -405,6 +413,13 @@ int unit_scale(miba_handle h) {
   hipLaunchKernelGGL(k_fill, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, 1.0, h->d_sp);
   HIPCHK(h, hipGetLastError());
   return MIBA_OK;
+}
+
+// unit Jacobi scale of an LM run without jacobi_scaling: still zero on constant blocks
+int unit_scale_masked(miba_handle h) {
+  int rc = unit_scale(h);
+  if (rc) return rc;
+  return apply_const_mask(h);
 }
 
 // ConjugateGradientsSolver::Solve on S y = rhs with x0 = 0.  Solution in d_px.
@@ -497,9 +512,9 @@ int backsub_and_candidate(miba_handle h) {
 
 int state_norm2(miba_handle h, double* out) {
   const int nb = 120;
-  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_cam, h->d_cam_active, 9, h->d_part_small);
+  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_cam, h->d_cam_active, 9, h->d_cfree, h->d_part_small);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 1, 0, 0, h->d_sum + S_XC2);
-  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_X, (const uint8_t*)nullptr, 3, h->d_part_small + 128);
+  hipLaunchKernelGGL(k_sumsq, dim3(nb), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_X, (const uint8_t*)nullptr, 3, (const double*)nullptr, h->d_part_small + 128);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small + 128, (size_t)nb, 1, 0, 0, h->d_sum + S_XP2);
   HIPCHK(h, hipGetLastError());
   int rc = allreduce(h, h->d_sum + S_XP2, 1, ncclSum);
@@ -528,7 +543,7 @@ int ensure_jacobian(miba_handle h, const miba_options* o) {
       if (rc) return rc;
     }
     if (!h->scale_valid) {
-      rc = o->jacobi_scaling ? make_scale_mf(h, o) : unit_scale(h);
+      rc = o->jacobi_scaling ? make_scale_mf(h, o) : unit_scale_masked(h);
       if (rc) return rc;
       h->scale_valid = true;
     }
@@ -542,7 +557,7 @@ int ensure_jacobian(miba_handle h, const miba_options* o) {
       rc = make_scale(h);
       if (rc) return rc;
     } else {
-      rc = unit_scale(h);
+      rc = unit_scale_masked(h);
       if (rc) return rc;
     }
     h->scale_valid = true;
@@ -832,7 +847,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   h->n_giant = (int32_t)giant.size();
   ALLOC(h->d_giant, giant.size());
   ALLOC(h->d_seg, segv.size()); ALLOC(h->d_cmo_pt, cmo_pt.size()); ALLOC(h->d_cmo_xy, cmo_xy.size());
-  ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_slabB, (size_t)kK2W * segv.size());
+  ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_cfree, 9 * nc); ALLOC(h->d_slabB, (size_t)kK2W * segv.size());
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
@@ -863,6 +878,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   UP(h->d_cam_seg_off, cam_seg_off.data(), nc + 1);
 #undef ALLOC
 #undef UP
+  hipLaunchKernelGGL(k_fill, dim3(nblk(9 * nc, 256)), dim3(256), 0, h->st, 9 * nc, 1.0, h->d_cfree);   // all blocks free
   HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
   HIPCHK(h, hipMemsetAsync(h->d_max, 0, S_COUNT * sizeof(double), h->st));
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(Ctl), h->st));
@@ -904,6 +920,21 @@ int miba_set_state(miba_handle h, const double* R, const double* T, const double
   if (rc) return rc;
   h->jac_valid = false;
   h->scale_valid = false;
+  return MIBA_OK;
+}
+
+int miba_set_constant_blocks(miba_handle h, const uint8_t* cam_const) {
+  if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> m(9 * (size_t)h->n_cam, 1.0);
+  if (cam_const)
+    for (int c = 0; c < h->n_cam; ++c)
+      for (int k = 0; k < 9; ++k)
+        if (cam_const[3 * (size_t)c + k / 3]) m[9 * (size_t)c + k] = 0.0;
+  int rc = upload(h, h->d_cfree, m.data(), m.size());
+  if (rc) return rc;
+  h->scale_valid = false;
+  h->jac_valid = false;
   return MIBA_OK;
 }
 

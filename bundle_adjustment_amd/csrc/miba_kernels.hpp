@@ -841,7 +841,7 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const ui
       Dc2[9 * (size_t)c + i] = d2;
       L[i * 9 + i] += d2;
       rhs[9 * (size_t)c + i] = a[45 + i];
-      if (active[c]) {
+      if (active[c] && sc[9 * (size_t)c + i] != 0.0) {       // scale 0: constant parameter block, not in the problem
         const double gu = a[54 + i] / sc[9 * (size_t)c + i];  // gradient of the unscaled problem
         gmax = fmax(gmax, fabs(gu));
         g2 += gu * gu;
@@ -927,6 +927,11 @@ __global__ void k_make_scale(size_t n, const double* __restrict__ n2, double* __
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) scale[i] = 1.0 / (1.0 + sqrt(n2[i]));
 }
+// a[i] *= m[i]  (constant-block mask onto the Jacobi scale)
+__global__ void k_mul(size_t n, const double* __restrict__ m, double* __restrict__ a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= m[i];
+}
 __global__ void k_fill(size_t n, double v, double* __restrict__ a) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(256) void k_cam_update(int n_cam, const double* __r
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 9 * (size_t)n_cam; i += (size_t)gridDim.x * blockDim.x) {
     const double c = cam[i] - yc[i] * sc[i];
     cand[i] = c;
-    if (active[i / 9]) {
+    if (active[i / 9] && sc[i] != 0.0) {   // constant blocks (scale 0) are not part of the reduced program's norms
       const double e = cam[i] - c;
       d2 += e * e;
       x2 += c * c;
@@ -954,11 +959,12 @@ __global__ __launch_bounds__(256) void k_cam_update(int n_cam, const double* __r
 
 // sum of squares of active entries (|x|^2 at start): stride = entries per block (9 cams / 3 pts)
 __global__ __launch_bounds__(256) void k_sumsq(size_t n, const double* __restrict__ a, const uint8_t* __restrict__ active, int per,
+                                               const double* __restrict__ keep /*0 = constant entry, or null*/,
                                                double* __restrict__ partial) {
   __shared__ double s4[4];
   double x2 = 0.0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    if (!active || active[i / per]) x2 += a[i] * a[i];
+    if ((!active || active[i / per]) && (!keep || keep[i] != 0.0)) x2 += a[i] * a[i];
   const double s = block_sum(x2, s4);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }

@@ -5,6 +5,8 @@
 // ceres::Solve (:108).  No per-observation cost-function objects are created on this path.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstdint>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -122,6 +124,22 @@ void BundleAdjustment::createProblem() {
     p.obs_pt = obs_pt.data();
     p.obs_xy = obs_xy.data();
     check(miba_set_problem(problem, &p), problem, "miba_set_problem");
+
+    // The reference's createProblem, in its checked-in debugging state, fixes the intrinsics and the rotation
+    // of every observed camera (src/BundleAdjustment.cpp:77-79) and all of camera 0 (:88-90).  The north-star
+    // configuration frees everything; BA_REFERENCE_CONSTANT_BLOCKS=1 reproduces the reference's marks.
+    const char *rc = getenv("BA_REFERENCE_CONSTANT_BLOCKS");
+    if (rc && rc[0] == '1') {
+        std::vector<uint8_t> cc(3 * (size_t) p.n_cam, 0);
+        for (int i = 0; i < n_obs; ++i) {
+            const int c = obs_cam[i];
+            if (obs_pt[i] == -1 || std::isnan(obs_xy[2 * (size_t) i]) || std::isnan(X[3 * (size_t) obs_pt[i]])) continue;
+            cc[3 * (size_t) c + 0] = 1;   // rotation
+            cc[3 * (size_t) c + 2] = 1;   // intrinsics
+        }
+        cc[0] = cc[1] = cc[2] = 1;        // fix 1st camera as reference
+        check(miba_set_constant_blocks(problem, cc.data()), problem, "miba_set_constant_blocks");
+    }
 
     std::cout << "Invalid observations: " << invalidObs << " out of " << dataset->getNumObservations() << std::endl;
     std::cout << "Creating problem end" << std::endl;

@@ -21,7 +21,7 @@ EXPORTS = [
     "miba_default_options", "miba_create", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
-    "miba_plan_shards", "miba_plan_point_owner", "miba_time_matvec",
+    "miba_plan_shards", "miba_plan_point_owner", "miba_time_matvec", "miba_set_constant_blocks",
 ]
 
 
@@ -212,6 +212,15 @@ class Solver:
         R, T, K = split_cams(cams)
         X = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
         self._chk(lib().miba_set_state(self._h, _dp(R), _dp(T), _dp(K), _dp(X)), "miba_set_state")
+
+    def set_constant_blocks(self, cam_const):
+        """cam_const: (n_cam, 3) flags for the rotation / translation / intrinsics block of every camera
+        (non-zero = constant), or None to free everything."""
+        if cam_const is None:
+            self._chk(lib().miba_set_constant_blocks(self._h, None), "miba_set_constant_blocks")
+            return
+        m = np.ascontiguousarray(np.asarray(cam_const).astype(np.uint8)).reshape(self.n_cam, 3)
+        self._chk(lib().miba_set_constant_blocks(self._h, m.ctypes.data_as(C.c_void_p)), "miba_set_constant_blocks")
 
     def get_state(self, cams_in=None, pts_in=None):
         """Returns (cams (n,9), pts (m,3)); blocks not in the problem keep the given input values."""

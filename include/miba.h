@@ -193,6 +193,14 @@ int miba_comm_unique_id(void* out128);
 
 int miba_set_problem(miba_handle h, const miba_problem* p);
 int miba_set_state(miba_handle h, const double* R, const double* T, const double* K, const double* X);
+
+/* Constant parameter blocks: replaces ceres::Problem::SetParameterBlockConstant as called at
+ * src/BundleAdjustment.cpp:77-79 (intrinsics and rotation of every observed camera) and :88-90 (camera 0).
+ * cam_const[3*c + {0,1,2}] != 0 marks the rotation / translation / intrinsics (f,k1,k2) block of camera c
+ * constant: its columns leave the problem (no step, no contribution to the gradient, step and parameter
+ * norms), as in Ceres' reduced program.  NULL frees every block (the default after miba_set_problem).
+ * Point blocks are always free, as in the reference. */
+int miba_set_constant_blocks(miba_handle h, const uint8_t* cam_const);
 int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X);
 
 /* Cost, and optionally residuals (2*n_obs), camera Jacobian blocks (18*n_obs, 2x9 row-major,

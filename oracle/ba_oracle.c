@@ -51,6 +51,7 @@ void bao_default_options(bao_options* o) {
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
   o->eta = 1e-1;
+  o->cam_const = NULL;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -751,6 +752,25 @@ static void clamp_diag(const prob_t* P, const bao_options* o, double* dc, double
   for (size_t i = 0; i < 3 * (size_t)P->n_pt; ++i) dp[i] = fmin(fmax(dp[i], o->min_lm_diagonal), o->max_lm_diagonal);
 }
 
+/* constant blocks: zero the entries of a camera-sized vector that belong to constant parameter blocks */
+static void mask_const(const prob_t* P, const unsigned char* cam_const, double* vc) {
+  if (!cam_const) return;
+  for (int c = 0; c < P->n_cam; ++c)
+    for (int k = 0; k < 9; ++k)
+      if (cam_const[3 * (size_t)c + k / 3]) vc[9 * (size_t)c + k] = 0.0;
+}
+/* |x|^2 over the free entries of the active blocks */
+static double free_sq(const prob_t* P, const unsigned char* cam_const, const double* vc, const double* vp) {
+  double s = 0.0;
+  for (int c = 0; c < P->n_cam; ++c)
+    if (P->cam_active[c])
+      for (int k = 0; k < 9; ++k)
+        if (!cam_const || !cam_const[3 * (size_t)c + k / 3]) s += vc[9 * (size_t)c + k] * vc[9 * (size_t)c + k];
+  for (int p = 0; p < P->n_pt; ++p)
+    if (P->pt_active[p]) for (int k = 0; k < 3; ++k) s += vp[3 * (size_t)p + k] * vp[3 * (size_t)p + k];
+  return s;
+}
+
 /* norms over ACTIVE parameter blocks only (inactive ones are not in the ceres::Problem) */
 static double active_sq(const prob_t* P, const double* vc, const double* vp) {
   double s = 0.0;
@@ -850,14 +870,21 @@ int bao_solve(int n_cam, int n_pt, int64_t n_obs, double* cams, double* pts,
   int consecutive_invalid = 0;
 
   /* IterationZero */
-  double x_norm = sqrt(active_sq(&P, xc, xp));
+  double x_norm = sqrt(free_sq(&P, opt->cam_const, xc, xp));
   double x_cost;
   {
     x_cost = prob_evaluate(&P, xc, xp, NULL, NULL, gc, gp);
+    mask_const(&P, opt->cam_const, gc);
     if (opt->jacobi_scaling) {
       prob_colnorm2(&P, sc, sp);
       for (size_t i = 0; i < nc9; ++i) sc[i] = 1.0 / (1.0 + sqrt(sc[i]));
       for (size_t i = 0; i < np3; ++i) sp[i] = 1.0 / (1.0 + sqrt(sp[i]));
+    } else {
+      for (size_t i = 0; i < nc9; ++i) sc[i] = 1.0;
+      for (size_t i = 0; i < np3; ++i) sp[i] = 1.0;
+    }
+    mask_const(&P, opt->cam_const, sc);   /* a zero scale removes the column from the scaled Jacobian */
+    if (opt->jacobi_scaling || opt->cam_const) {
       /* scale the stored Jacobian in place */
 #pragma omp parallel for schedule(static) num_threads(P.n_thr)
       for (int p = 0; p < n_pt; ++p)
@@ -866,9 +893,6 @@ int bao_solve(int n_cam, int n_pt, int64_t n_obs, double* cams, double* pts,
           for (int k = 0; k < 9; ++k) { P.F[18 * s + k] *= sc[9 * c + k]; P.F[18 * s + 9 + k] *= sc[9 * c + k]; }
           for (int k = 0; k < 3; ++k) { P.E[6 * s + k] *= sp[3 * (size_t)p + k]; P.E[6 * s + 3 + k] *= sp[3 * (size_t)p + k]; }
         }
-    } else {
-      for (size_t i = 0; i < nc9; ++i) sc[i] = 1.0;
-      for (size_t i = 0; i < np3; ++i) sp[i] = 1.0;
     }
   }
   double minimum_cost = x_cost;
@@ -980,8 +1004,9 @@ int bao_solve(int n_cam, int n_pt, int64_t n_obs, double* cams, double* pts,
       /* HandleSuccessfulStep */
       memcpy(xc, cc, sizeof(double) * nc9);
       memcpy(xp, cp, sizeof(double) * np3);
-      x_norm = sqrt(active_sq(&P, xc, xp));
+      x_norm = sqrt(free_sq(&P, opt->cam_const, xc, xp));
       x_cost = prob_evaluate(&P, xc, xp, sc, sp, gc, gp);
+      mask_const(&P, opt->cam_const, gc);
       it.cost = x_cost;
       it.gradient_max_norm = active_max(&P, gc, gp);
       it.gradient_norm = sqrt(active_sq(&P, gc, gp));

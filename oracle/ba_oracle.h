@@ -58,6 +58,9 @@ typedef struct {
   double gradient_tolerance;           /* 1e-10 */
   double parameter_tolerance;          /* 1e-8 */
   double eta;                          /* 1e-1 */
+  /* constant parameter blocks (ceres::Problem::SetParameterBlockConstant, src/BundleAdjustment.cpp:77-79,88-90):
+     [n_cam][3] flags for (rotation, translation, intrinsics), non-zero = constant; NULL = all free */
+  const unsigned char* cam_const;
 } bao_options;
 
 typedef struct {

@@ -63,7 +63,7 @@ def default_options():
                 max_trust_region_radius=1e16, min_trust_region_radius=1e-32,
                 min_relative_decrease=1e-3, min_lm_diagonal=1e-6, max_lm_diagonal=1e32,
                 function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8,
-                max_num_consecutive_invalid_steps=5)
+                max_num_consecutive_invalid_steps=5, cam_const=None)
 
 
 def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
@@ -88,14 +88,26 @@ def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
         r = residuals(c, p, obs_cam, obs_pt, obs_xy).ravel()
         return 0.5 * r @ r, r
 
+    # constant parameter blocks (ceres::Problem::SetParameterBlockConstant, src/BundleAdjustment.cpp:77-79,88-90):
+    # cam_const[c] = (rotation, translation, intrinsics) flags; constant columns are removed from the program
+    free = np.ones(np3 + 9 * n_cam, bool)
+    cc = o.pop("cam_const", None)
+    if cc is not None:
+        cc = np.asarray(cc, bool).reshape(n_cam, 3)
+        free[np3:] = ~np.repeat(cc, 3, axis=1).ravel()
+    jac_full = jacobian
+
+    def jacobian_free(c, p, oc, op, oxy):
+        return jac_full(c, p, oc, op, oxy)[:, free]
+
     x = pack(cams, pts)
     radius, decrease_factor, reuse_diag = o["initial_trust_region_radius"], 2.0, False
     x_cost, r = evaluate(x)
-    J = jacobian(*unpack(x), obs_cam, obs_pt, obs_xy)
+    J = jacobian_free(*unpack(x), obs_cam, obs_pt, obs_xy)
     g = J.T @ r
     scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0))) if o["jacobi_scaling"] else np.ones(J.shape[1])
     J = J * scale
-    x_norm = np.linalg.norm(x)
+    x_norm = np.linalg.norm(x[free])
     best_x, min_cost = x.copy(), x_cost
     it = dict(iteration=0, cost=x_cost, cost_change=0.0, gradient_max_norm=np.abs(g).max(),
               gradient_norm=np.linalg.norm(g), step_norm=0.0, relative_decrease=0.0,
@@ -144,7 +156,8 @@ def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
             radius *= 0.5
             continue
         invalid = 0
-        delta = step * scale
+        delta = np.zeros_like(x)
+        delta[free] = step * scale
         x_cand = x + delta
         cand_cost, _ = evaluate(x_cand)
         if not np.isfinite(cand_cost):
@@ -158,9 +171,9 @@ def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
             termination = "CONVERGENCE"; its.append(dict(it)); break
         if it["relative_decrease"] > o["min_relative_decrease"]:
             x = x_cand
-            x_norm = np.linalg.norm(x)
+            x_norm = np.linalg.norm(x[free])
             x_cost, r = evaluate(x)
-            J = jacobian(*unpack(x), obs_cam, obs_pt, obs_xy)
+            J = jacobian_free(*unpack(x), obs_cam, obs_pt, obs_xy)
             g = J.T @ r
             J = J * scale
             it.update(cost=x_cost, gradient_max_norm=np.abs(g).max(), gradient_norm=np.linalg.norm(g),

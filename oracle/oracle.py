@@ -35,6 +35,7 @@ class Options(C.Structure):
         ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),
         ("eta", C.c_double),
+        ("cam_const", C.c_void_p),
     ]
 
 
@@ -101,6 +102,11 @@ def _i32(a):
 def default_options(**kw):
     o = Options()
     lib().bao_default_options(C.byref(o))
+    cc = kw.pop("cam_const", None)
+    if cc is not None:
+        # [n_cam][3] flags (rotation, translation, intrinsics); the array is kept alive on the options object
+        o._cam_const = np.ascontiguousarray(np.asarray(cc).astype(np.uint8))
+        o.cam_const = o._cam_const.ctypes.data
     for k, v in kw.items():
         if not hasattr(o, k):
             raise AttributeError(k)

@@ -297,3 +297,46 @@ def test_k2_one_pass_matches_two_pass(medium):
     assert rel(a["rhs"], b["rhs"]) <= 1e-11 and rel(a["Sv"], b["Sv"]) <= 1e-11
     assert a["n_cg"] == b["n_cg"]
     assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
+
+
+@pytest.mark.parametrize("name", ["lm_tiny_c.json", "lm_tiny_d.json"])
+def test_constant_blocks_match_golden_and_oracle(oracle, name):
+    """miba_set_constant_blocks (ceres SetParameterBlockConstant, src/BundleAdjustment.cpp:77-79,88-90) against the
+    numpy dense-LM fixture (lm_tiny_c: the reference's own marks) and the C oracle run the same way."""
+    g = json.load(open(os.path.join(GOLD, name)))
+    fh = lambda xs: np.array([float.fromhex(h) for h in xs])
+    cams0, pts0 = fh(g["cams0_hex"]).reshape(-1, 9), fh(g["pts0_hex"]).reshape(-1, 3)
+    oc, op = np.array(g["obs_cam"], dtype=np.int32), np.array(g["obs_pt"], dtype=np.int32)
+    oxy = fh(g["obs_xy_hex"]).reshape(-1, 2)
+    cc = np.array(g["cam_const"], dtype=np.uint8)
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams0, pts0, oc, op, oxy)
+    s.set_constant_blocks(cc)
+    its, summ = s.solve(miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, max_num_iterations=g["max_num_iterations"]))
+    cams, pts = s.get_state(cams0, pts0)
+    # the same run with the PCG stopping rule of ITERATIVE_SCHUR, against the C oracle
+    s.set_state(cams0, pts0)
+    its2, summ2 = s.solve(miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, max_num_iterations=g["max_num_iterations"]))
+    s.close()
+    gold = g["iterations"]
+    n_cmp = 1
+    while n_cmp < len(gold) and abs(gold[n_cmp]["cost_change"]) > 1e-8 * gold[n_cmp]["cost"]:
+        n_cmp += 1
+    assert n_cmp >= 3 and len(its) >= n_cmp
+    for a, b in zip(its[:n_cmp], gold[:n_cmp]):
+        assert abs(a["cost"] - b["cost"]) <= REL_COST * b["cost"], (a, b)
+        assert bool(a["step_is_successful"]) == b["step_is_successful"]
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-4 * b["gradient_max_norm"] + 1e-9
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-3 * b["step_norm"] + 1e-12
+    assert abs(summ["final_cost"] - g["final_cost"]) <= REL_COST * g["final_cost"]
+    # constant blocks did not move
+    mask9 = np.repeat(cc.astype(bool), 3, axis=1)
+    assert np.array_equal(cams[mask9], cams0[mask9])
+    assert not np.array_equal(cams[~mask9], cams0[~mask9])
+    _, _, oits, osumm = oracle.solve(cams0, pts0, oc, op, oxy,
+                                     oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR,
+                                                            max_num_iterations=g["max_num_iterations"], cam_const=cc))
+    assert len(its2) == len(oits)
+    for a, b in zip(its2, oits):
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
+        assert a["linear_solver_iterations"] == b["linear_solver_iterations"]

@@ -101,3 +101,23 @@ def test_app_main_end_to_end(tmp_path, oracle):
     head = open(tmp_path / "constrainTransReal.ply").read().split("\n")
     assert head[0] == "ply" and head[2] == "element vertex %d" % (600 + 20)
     assert head[10].endswith(" 0 255 0") and "Solver Summary" in out.stdout
+
+
+@pytest.mark.gpu
+def test_app_main_reference_constant_blocks(tmp_path, oracle):
+    """BA_REFERENCE_CONSTANT_BLOCKS=1: createProblem marks what the reference marks (src/BundleAdjustment.cpp:77-79,
+    88-90: rotation + intrinsics of every camera, all of camera 0); final cost against the oracle with the same mask."""
+    pr = synth.make_problem(20, 600, 2600, seed=5)
+    path = str(tmp_path / "problem-20-600-pre.txt")
+    synth.write_bal(path, pr)
+    env = dict(os.environ, BA_SIGMA_CAM="0.005", BA_SIGMA_X="0.05", BA_ITERATION_PLY="0", BA_REFERENCE_CONSTANT_BLOCKS="1")
+    out = subprocess.run([MAIN, path, "SPARSE_SCHUR", "10"], capture_output=True, text=True, timeout=120, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    final = float(re.search(r"FINAL_COST (\S+) ITERATIONS (\d+)", out.stdout).group(1))
+    R, T, K, X = oracle.bal_initialize(pr["cams"].astype(np.float32), pr["pts"].astype(np.float32), 0.005, 0.05, seed=1)
+    cams0 = np.concatenate([R, T, K[:, 0:1], K[:, 4:5], K[:, 5:6]], 1)
+    cc = np.zeros((20, 3), np.uint8)
+    cc[:, 0] = 1; cc[:, 2] = 1; cc[0, :] = 1
+    _, _, oits, osumm = oracle.solve(cams0, X, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"],
+                                     oracle.default_options(max_num_iterations=10, linear_solver=oracle.DENSE_SCHUR, cam_const=cc))
+    assert abs(final - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"], (final, osumm)

@@ -54,13 +54,15 @@ def _load_lm(name):
             np.array(g["obs_pt"], dtype=np.int32), fh(g["obs_xy_hex"]).reshape(-1, 2))
 
 
-@pytest.mark.parametrize("name", ["lm_tiny_a.json", "lm_tiny_b.json"])
+@pytest.mark.parametrize("name", ["lm_tiny_a.json", "lm_tiny_b.json", "lm_tiny_c.json", "lm_tiny_d.json"])
 @pytest.mark.parametrize("solver", ["normal", "schur", "pcg"])
 def test_lm_table_matches_numpy_dense_lm(oracle, name, solver):
     g, cams0, pts0, oc, op, oxy = _load_lm(name)
     ls = {"normal": oracle.DENSE_NORMAL, "schur": oracle.DENSE_SCHUR, "pcg": oracle.ITERATIVE_SCHUR}[solver]
+    # lm_tiny_c / _d carry constant parameter blocks (c: the marks of src/BundleAdjustment.cpp:77-79,88-90)
     o = oracle.default_options(max_num_iterations=g["max_num_iterations"], linear_solver=ls,
-                               eta=1e-14 if solver == "pcg" else 0.1, max_linear_solver_iterations=5000)
+                               eta=1e-14 if solver == "pcg" else 0.1, max_linear_solver_iterations=5000,
+                               cam_const=g.get("cam_const"))
     cams, pts, its, summ = oracle.solve(cams0, pts0, oc, op, oxy, o)
     gold = g["iterations"]
     tol = 1e-4 if solver == "pcg" else 1e-9   # Q-tolerance PCG is inexact in weakly determined directions
@@ -68,7 +70,7 @@ def test_lm_table_matches_numpy_dense_lm(oracle, name, solver):
     n_cmp = 1
     while n_cmp < len(gold) and abs(gold[n_cmp]["cost_change"]) > 1e-8 * gold[n_cmp]["cost"]:
         n_cmp += 1
-    assert n_cmp >= 4 and len(its) >= n_cmp
+    assert n_cmp >= 3 and len(its) >= n_cmp
     for a, b in zip(its[:n_cmp], gold[:n_cmp]):
         assert a["iteration"] == b["iteration"]
         assert abs(a["cost"] - b["cost"]) <= tol * b["cost"]

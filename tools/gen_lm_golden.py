@@ -15,17 +15,37 @@ sys.path.insert(0, ROOT)
 from bundle_adjustment_amd import synth  # noqa: E402
 from oracle import dense_lm  # noqa: E402
 
-CASES = [("lm_tiny_a", 8, 20, 70, 101, 0.01, 0.2, 12), ("lm_tiny_b", 12, 60, 260, 3, 0.01, 0.3, 15)]
+# last field: constant-block pattern: None = all free; "reference" = what src/BundleAdjustment.cpp:77-79,88-90 marks
+# (rotation and intrinsics of every camera, plus all of camera 0); "mixed" = an arbitrary pattern
+CASES = [("lm_tiny_a", 8, 20, 70, 101, 0.01, 0.2, 12, None), ("lm_tiny_b", 12, 60, 260, 3, 0.01, 0.3, 15, None),
+         ("lm_tiny_c", 8, 20, 70, 101, 0.01, 0.2, 12, "reference"), ("lm_tiny_d", 12, 60, 260, 3, 0.01, 0.3, 15, "mixed")]
 
-for name, n_cam, n_pt, n_obs, seed, s_cam, s_x, n_it in CASES:
+
+def const_pattern(kind, n_cam):
+    if kind is None:
+        return None
+    cc = np.zeros((n_cam, 3), bool)
+    if kind == "reference":
+        cc[:, 0] = True; cc[:, 2] = True; cc[0, :] = True
+    else:
+        rng = np.random.default_rng(77)
+        cc[:] = rng.random((n_cam, 3)) < 0.3
+        cc[0, :] = True
+    return cc
+
+
+for name, n_cam, n_pt, n_obs, seed, s_cam, s_x, n_it, ckind in CASES:
     pr = synth.make_problem(n_cam, n_pt, n_obs, seed=seed)
     cams0, pts0 = synth.perturb(pr, s_cam, s_x, seed=seed + 1)
-    cams, pts, its, summ = dense_lm.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], max_num_iterations=n_it)
+    cc = const_pattern(ckind, n_cam)
+    cams, pts, its, summ = dense_lm.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], max_num_iterations=n_it,
+                                          cam_const=cc)
     keys = ["iteration", "cost", "cost_change", "gradient_max_norm", "gradient_norm", "step_norm",
             "relative_decrease", "trust_region_radius", "step_is_valid", "step_is_successful"]
     out = {
         "generator": "tools/gen_lm_golden.py (oracle/dense_lm.py)",
         "n_cam": n_cam, "n_pt": n_pt, "n_obs": n_obs, "max_num_iterations": n_it,
+        "cam_const": None if cc is None else cc.astype(int).tolist(),
         "cams0_hex": [float(v).hex() for v in cams0.ravel()],
         "pts0_hex": [float(v).hex() for v in pts0.ravel()],
         "obs_cam": pr["obs_cam"].tolist(), "obs_pt": pr["obs_pt"].tolist(),
@@ -36,6 +56,9 @@ for name, n_cam, n_pt, n_obs, seed, s_cam, s_x, n_it in CASES:
         "pts_final_hex": [float(v).hex() for v in pts.ravel()],
     }
     path = os.path.join(ROOT, "tests", "golden", name + ".json")
+    if os.path.exists(path) and "--force" not in sys.argv:
+        print(name, "exists, kept (dense BLAS results differ in the last bits from run to run; --force rewrites)")
+        continue
     with open(path, "w") as fh:
         json.dump(out, fh)
     print(name, summ, len(its))
