@@ -1,6 +1,8 @@
 // Prints residual and autodiff Jacobian of BAConstraint::create(...) for records read from stdin
 // ("cam9 X3 obs2" per line, 14 hex/decimal doubles): the host-side functor checked against the
 // mpmath fixtures by tests/test_host_cpp.py.  Needs no GPU.
+#include <chrono>
+#include <fstream>
 #include <cstdio>
 #include <iostream>
 #include <memory>
@@ -29,7 +31,29 @@ static int dump_loader(const char *path) {
     return 0;
 }
 
+// "--loader-time <file>": seconds spent in the BalDataloader constructor, and the same file through the
+// reference's serial `ifstream >>` loop (src/BalDataloader.cpp:21-58) for comparison
+static int time_loader(const char *path) {
+    auto t0 = std::chrono::steady_clock::now();
+    BalDataloader d(path);
+    const double fast = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    t0 = std::chrono::steady_clock::now();
+    std::ifstream file(path);
+    int nc, np, no;
+    file >> nc >> np >> no;
+    double chk = 0.0;
+    for (int i = 0; i < no; ++i) { int c, p; float x, y; file >> c >> p >> x >> y; chk += x; }
+    for (long long i = 0; i < 9LL * nc + 3LL * np; ++i) { float v; file >> v; chk += v; }
+    const double serial = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("cameras %d points %d observations %d fast_s %.3f serial_ifstream_s %.3f speedup %.1f checksum %g\n", d.getNumFrames(),
+           d.getNumPoints(), d.getNumObservations(), fast, serial, serial / fast, chk);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 3 && std::string(argv[1]) == "--loader-time") {
+        try { return time_loader(argv[2]); } catch (const std::invalid_argument &e) { printf("invalid_argument %s\n", e.what()); return 3; }
+    }
     if (argc == 3 && std::string(argv[1]) == "--loader") {
         try { return dump_loader(argv[2]); } catch (const std::invalid_argument &e) { printf("invalid_argument %s\n", e.what()); return 3; }
     }

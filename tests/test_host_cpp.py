@@ -121,3 +121,37 @@ def test_app_main_reference_constant_blocks(tmp_path, oracle):
     _, _, oits, osumm = oracle.solve(cams0, X, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"],
                                      oracle.default_options(max_num_iterations=10, linear_solver=oracle.DENSE_SCHUR, cam_const=cc))
     assert abs(final - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"], (final, osumm)
+
+
+def test_bal_loader_threaded_parse_equals_serial(tmp_path):
+    """The multi-threaded from_chars parser against the same parser on one thread, on a file large
+    enough (> 1 MiB) to be cut into ranges; also '+'-signed numbers, CRLF line ends and a truncated file."""
+    pr = synth.make_problem(30, 6000, 26000, seed=8)
+    path = str(tmp_path / "problem-30-6000-pre.txt")
+    synth.write_bal(path, pr)
+    txt = open(path).read()
+    assert len(txt) > (1 << 20)
+    outs = []
+    for thr in ("1", "7"):
+        out = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=120,
+                             env=dict(os.environ, BA_LOADER_THREADS=thr))
+        assert out.returncode == 0, out.stderr
+        outs.append(out.stdout)
+    assert outs[0] == outs[1]
+    tok = outs[0].split("\n")
+    assert tok[0].split() == ["30", "6000", "26000"]
+    c, p, x, y = tok[26000].split()   # last observation
+    assert (int(c), int(p)) == (pr["obs_cam"][-1], pr["obs_pt"][-1])
+    assert float.fromhex(x) == float(np.float32(pr["obs_xy"][-1, 0]))
+    # '+' signs and CRLF
+    lines = txt.split("\n")
+    lines[1] = " ".join(("+" + t if not t.startswith("-") and i >= 2 else t) for i, t in enumerate(lines[1].split()))
+    p2 = str(tmp_path / "crlf.txt")
+    open(p2, "w", newline="").write("\r\n".join(lines))
+    out = subprocess.run([CHECK, "--loader", p2], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout == outs[0]
+    # truncated
+    p3 = str(tmp_path / "trunc.txt")
+    open(p3, "w").write(txt[: len(txt) // 2])
+    out = subprocess.run([CHECK, "--loader", p3], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and "truncated" in out.stdout
