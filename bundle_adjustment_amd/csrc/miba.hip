@@ -195,7 +195,8 @@ int sync_stream(miba_handle h) {
   return MIBA_OK;
 }
 
-inline int nblk(size_t n, int bs) { return (int)((n + bs - 1) / bs); }
+// blocks for n items; never 0 (an empty shard still launches one block whose bounds checks do nothing)
+inline int nblk(size_t n, int bs) { return n ? (int)((n + bs - 1) / bs) : 1; }
 
 int allreduce(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
   if (!h->comm) return MIBA_OK;
@@ -657,7 +658,10 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
     return rc;
   }
   const char* force = getenv("MIBA_FORCE_RCCL");
-  if (cfg->world_size > 1 || (force && force[0] == '1')) {
+  // MIBA_TEST_NO_COMM=1 (tests only): a rank of a multi-rank world without a communicator, so that its
+  // un-reduced partial sums can be inspected on a single GPU; solves are meaningless in this mode
+  const char* nocomm = getenv("MIBA_TEST_NO_COMM");
+  if ((cfg->world_size > 1 && !(nocomm && nocomm[0] == '1')) || (force && force[0] == '1')) {
     ncclUniqueId id;
     if (cfg->comm_unique_id) memcpy(&id, cfg->comm_unique_id, sizeof(id));
     else if (cfg->world_size == 1) {
