@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--eta", type=float, default=0.1)
     ap.add_argument("--check-every", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--ttt", type=int, default=0, help="also report time-to-cost-tolerance over at most this many LM iterations")
     args = ap.parse_args()
 
