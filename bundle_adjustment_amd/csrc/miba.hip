@@ -735,6 +735,12 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     return fail(h, MIBA_ERR_INVALID, "null problem array");
   HIPCHK(h, hipSetDevice(h->device));
   free_problem(h);
+  {
+    const char* mf = getenv("MIBA_MF");   // matrix-free kernels are the default; MIBA_MF=0 selects the stored-Jacobian path
+    h->use_mf = !(mf && mf[0] == '0');
+    const char* op = getenv("MIBA_K2_ONEPASS");
+    h->k2_onepass = op && op[0] == '1';
+  }
   const char* po = getenv("MIBA_POINT_ORDER");
   Plan& P = h->plan;
   int rc = build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->cfg.world_size,
@@ -855,7 +861,8 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
-  ALLOC(h->d_slab64, (size_t)kK2W * n_rows); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
+  // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
+  ALLOC(h->d_slab64, (!h->use_mf || h->k2_onepass) ? (size_t)kK2W * n_rows : (size_t)1); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
   ALLOC(h->d_camacc, (size_t)kK2W * nc); ALLOC(h->d_Minv, 81 * nc); ALLOC(h->d_Dc2, 9 * nc); ALLOC(h->d_rhs, 9 * nc);
   ALLOC(h->d_px, 9 * nc); ALLOC(h->d_pr, 9 * nc); ALLOC(h->d_pz, 9 * nc); ALLOC(h->d_pp, 9 * nc); ALLOC(h->d_pq, 9 * nc);
   ALLOC(h->d_probe, 9 * nc);
@@ -892,12 +899,6 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   std::vector<int32_t>().swap(P.idx);
   std::vector<int32_t>().swap(P.ocam);
   h->has_problem = true;
-  {
-    const char* mf = getenv("MIBA_MF");   // matrix-free kernels are the default; MIBA_MF=0 selects the stored-Jacobian path
-    h->use_mf = !(mf && mf[0] == '0');
-    const char* op = getenv("MIBA_K2_ONEPASS");
-    h->k2_onepass = op && op[0] == '1';
-  }
   memset(&h->kt, 0, sizeof(h->kt));
   return miba_set_state(h, p->R, p->T, p->K, p->X);
 }
