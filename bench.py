@@ -139,14 +139,21 @@ def main():
         ms = kt["total_ms"][kid] / max(1, n)
         kern[nm] = {"launches": n, "avg_ms": round(ms, 4), "algorithmic_GBs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
     # HBM traffic of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE)
-    traffic = None
+    traffic, pipes = None, None
     tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
     if mf and args.gpus == 1 and args.config == "final-13682" and os.path.exists(tpath):
         with open(tpath) as fh:
-            traffic = json.load(fh).get("k_mf_matvec", {}).get("traffic_bytes_per_launch")
+            pm = json.load(fh).get("k_mf_matvec", {})
+        traffic = pm.get("traffic_bytes_per_launch")
+        if "valu_busy_frac" in pm:
+            pipes = {"valu_busy_frac": pm["valu_busy_frac"], "lds_busy_frac": pm.get("lds_busy_frac"),
+                     "waves_per_simd": pm.get("waves_resident_per_simd"),
+                     "source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc SQ_* passes of the same kernel)"}
     roof = {"bound": "hbm", "kernel": "k_mf_matvec (K3-mf)" if mf else "k_schur_matvec<0> (K3)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": k3_ms,
             "launches": k3_n, "launches_including_early_exits": k3_all, "algorithmic_bytes_per_launch": k3_bytes}
+    if pipes:
+        roof["measured_pipe_utilisation"] = pipes
     if mf:
         # The matrix-free product trades HBM bytes for fp64 work: it is bound by the vector fp64 / LDS pipes, not by
         # HBM.  Two extra views: the fp64 rate against the vector peak, and the bytes a stored-Jacobian product
