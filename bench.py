@@ -73,39 +73,63 @@ def main():
     solver.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
     t_setup = time.time() - t0
 
-    total = args.warmup + args.steps
-    opt = miba.default_options(max_num_iterations=total, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
-                               function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
-                               pcg_check_every=args.check_every)
-    marks = {}
-
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def cb(it):
-        if it.iteration == args.warmup:
-            sync()
-            solver.reset_kernel_times()
-            marks["t0"] = time.perf_counter()
-        if it.iteration == total:
-            sync()
-            marks["t1"] = time.perf_counter()
-        return 0
+    # Exactly --steps timed LM iterations after --warmup untimed ones.  Normally that is one miba_solve call; if the
+    # solver stops early (it can converge or fail before a large --steps is reached even with zero tolerances), the
+    # state is reset to the initial one outside the timed region and the count continues in another call.
+    warm_left, steps_left, dt = args.warmup, args.steps, 0.0
+    its, timed, summ, first_its = [], [], None, None
+    timing_started = False
+    while steps_left > 0:
+        n_this = warm_left + steps_left
+        opt = miba.default_options(max_num_iterations=n_this, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
+                                   function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
+                                   pcg_check_every=args.check_every)
+        marks = {}
 
-    its, summ = solver.solve(opt, callback=cb)
-    if "t0" not in marks or "t1" not in marks:
-        raise SystemExit("solver stopped before %d iterations: %s" % (total, summ["message"]))
-    dt = marks["t1"] - marks["t0"]
+        def cb(it, warm=warm_left, n=n_this):
+            if it.iteration == warm:
+                sync()
+                if not timing_started:
+                    solver.reset_kernel_times()
+                marks["t0"] = time.perf_counter()
+            if it.iteration == n:
+                sync()
+                marks["t1"] = time.perf_counter()
+            return 0
+
+        seg, summ = solver.solve(opt, callback=cb)
+        sync()
+        t_end = time.perf_counter()
+        if first_its is None:
+            first_its = seg
+        n_end = seg[-1]["iteration"]
+        if "t0" in marks:
+            timing_started = True
+            dt += marks.get("t1", t_end) - marks["t0"]
+            done = n_end - warm_left
+            timed += [r for r in seg if warm_left < r["iteration"] <= n_end]
+            steps_left -= done
+            warm_left = 0
+        else:
+            warm_left -= n_end
+        its += seg
+        if steps_left > 0:
+            if n_end == 0:
+                raise SystemExit("solver made no iteration: %s" % summ["message"])
+            solver.set_state(cams0, pts0)
+    total = args.warmup + args.steps
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kt = solver.kernel_times()
 
-    timed = [r for r in its if args.warmup < r["iteration"] <= total]
     n_cg = sum(r["linear_solver_iterations"] for r in timed)
     mf = os.environ.get("MIBA_MF", "1") != "0"
     # Algorithmic bytes per launch (DESIGN.md "Kernels"): o = this rank's observations, m = its points, n = cameras.
@@ -236,16 +260,17 @@ def main():
         oo = O.default_options(max_num_iterations=args.cpu_iters, linear_solver=O.ITERATIVE_SCHUR, eta=args.eta,
                                function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0, num_threads=cores)
         _, _, oits, osumm = O.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], oo)
-        t_cpu = sum(r["iteration_time_s"] for r in oits[1:])
-        n_cpu = len(oits) - 1
-        same = [abs(a["cost"] - b["cost"]) / b["cost"] for a, b in zip(its[1:1 + n_cpu], oits[1:])]
-        t_gpu_same = sum(r["iteration_time_in_seconds"] for r in its[1:1 + n_cpu])
+        # compare on the iterations both runs have (the first miba_solve call starts from the same state)
+        n_cpu = min(len(oits), len(first_its)) - 1
+        t_cpu = sum(r["iteration_time_s"] for r in oits[1:1 + n_cpu])
+        same = [abs(a["cost"] - b["cost"]) / b["cost"] for a, b in zip(first_its[1:1 + n_cpu], oits[1:])]
+        t_gpu_same = sum(r["iteration_time_in_seconds"] for r in first_its[1:1 + n_cpu])
         out["cpu_baseline"] = {"value": n_cpu / t_cpu if t_cpu > 0 else None, "unit": "LM iterations/s", "cores": cores,
                                "kind": "port",
                                "hip_value_on_same_sample": n_cpu / t_gpu_same if t_gpu_same > 0 else None,
                                "sample": "first %d LM iteration(s) of the same problem and initial state (%d PCG iterations), "
                                          "oracle/ba_oracle.c with OpenMP; cost after them agrees with the HIP path to %.1e relative"
-                                         % (n_cpu, sum(r["linear_solver_iterations"] for r in oits[1:]), max(same) if same else 0.0)}
+                                         % (n_cpu, sum(r["linear_solver_iterations"] for r in oits[1:1 + n_cpu]), max(same) if same else 0.0)}
     if rank == 0:
         print(json.dumps(out))
     solver.close()
