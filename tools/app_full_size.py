@@ -1,0 +1,28 @@
+"""End-to-end run of the C++ mirror (app/ba_main: BalDataloader -> BundleAdjustment -> libmiba) on a BAL text file of
+a named configuration written to the temp directory.  usage: app_full_size.py [config] [solver] [iterations]"""
+import os, re, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from bundle_adjustment_amd import synth
+cfg = sys.argv[1] if len(sys.argv) > 1 else "final-13682"
+solver = sys.argv[2] if len(sys.argv) > 2 else "ITERATIVE_SCHUR"
+iters = sys.argv[3] if len(sys.argv) > 3 else "80"
+n_cam, n_pt, n_obs, seed = synth.CONFIGS[cfg]
+t = time.time()
+pr = synth.make_problem(n_cam, n_pt, n_obs, seed=seed)
+print("generated in %.1f s" % (time.time() - t), flush=True)
+d = tempfile.mkdtemp()
+path = os.path.join(d, "problem-%d-%d-pre.txt" % (n_cam, n_pt))
+t = time.time()
+synth.write_bal(path, pr)
+print("wrote %.1f MB in %.1f s" % (os.path.getsize(path) / 1e6, time.time() - t), flush=True)
+exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'app', 'ba_main')
+env = dict(os.environ, BA_ITERATION_PLY="0", BA_SIGMA_CAM=os.environ.get("BA_SIGMA_CAM", "0.001"),
+           BA_SIGMA_X=os.environ.get("BA_SIGMA_X", "0.05"), BA_LOADER_DEBUG="1")
+t = time.time()
+out = subprocess.run([exe, path, solver, iters], capture_output=True, text=True, cwd=d, env=env)
+print("ba_main: rc %d, %.1f s wall" % (out.returncode, time.time() - t))
+print(out.stderr[-1500:])
+lines = out.stdout.split("\n")
+keep = [l for l in lines if re.search(r"FINAL_COST|Solver Summary|Cost:|Initial|Final|Termination|iterations|Time|Linear solver|Minimizer|Residual|Jacobian|Total|Creating|Solving|Invalid", l)]
+print("\n".join(keep[-60:]))
+os.remove(path)
