@@ -40,8 +40,22 @@ def main():
     ap.add_argument("--ttt", type=int, default=0, help="also report time-to-cost-tolerance over at most this many LM iterations")
     args = ap.parse_args()
 
+    import ctypes
+
     import torch
     from bundle_adjustment_amd import miba, synth
+
+    # RCCL prints a version banner on C stdout when the first communicator is made.  The contract is ONE JSON line on
+    # stdout, so file descriptor 1 points at stderr until the line is printed.
+    sys.stdout.flush()
+    libc = ctypes.CDLL(None)
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def restore_stdout():
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved_stdout, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -271,8 +285,10 @@ def main():
                                "sample": "first %d LM iteration(s) of the same problem and initial state (%d PCG iterations), "
                                          "oracle/ba_oracle.c with OpenMP; cost after them agrees with the HIP path to %.1e relative"
                                          % (n_cpu, sum(r["linear_solver_iterations"] for r in oits[1:1 + n_cpu]), max(same) if same else 0.0)}
+    restore_stdout()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)   # anything the libraries still print on the way out is not part of the result
     solver.close()
     if dist is not None:
         dist.barrier()

@@ -351,10 +351,13 @@ int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* pa
                          h->d_sc, h->d_X, h->d_ptrec, x, h->d_slab9, ctl);
     }
     hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
-                       h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, h->comm ? (double*)nullptr : part_xy,
-                       ctl);
+                       h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, part_xy, ctl);
     HIPCHK(h, hipGetLastError());
-    return allreduce(h, y, 9 * (size_t)h->n_cam, ncclSum);
+    // x.y is linear in y, so with several ranks the per-block partials of x.y_local are all-reduced together with
+    // y_local (the caller places them right behind y): every rank then sums the same red_nb numbers
+    const bool tail = part_xy && part_xy == y + 9 * (size_t)h->n_cam;
+    if (h->comm && part_xy && !tail) return fail(h, MIBA_ERR_INVALID, "x.y partials must follow y for the all-reduce");
+    return allreduce(h, y, 9 * (size_t)h->n_cam + (tail ? (size_t)h->red_nb : 0), ncclSum);
   }
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_MATVEC);
@@ -432,8 +435,8 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
   double* part_nb = h->d_part_pcg;
   double* part_q = h->d_part_pcg + kPcgMaxBlocks;
   double* part_rho[2] = {h->d_part_pcg + 2 * kPcgMaxBlocks, h->d_part_pcg + 3 * kPcgMaxBlocks};
-  double* part_pq = h->d_part_pcg + 4 * kPcgMaxBlocks;
-  const bool fused_pq = h->use_mf && !h->comm;
+  const bool fused_pq = h->use_mf;   // the camera reduction of the matrix-free product leaves the p.q partials
+  double* part_pq = fused_pq ? h->d_pq + n : h->d_part_pcg + 4 * kPcgMaxBlocks;   // behind q: one all-reduce for both
   const int n_pq = fused_pq ? h->red_nb : kPcgBlocks;
   hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
                      part_nb, part_rho[1]);
@@ -864,7 +867,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
   ALLOC(h->d_slab64, (!h->use_mf || h->k2_onepass) ? (size_t)kK2W * n_rows : (size_t)1); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
   ALLOC(h->d_camacc, (size_t)kK2W * nc); ALLOC(h->d_Minv, 81 * nc); ALLOC(h->d_Dc2, 9 * nc); ALLOC(h->d_rhs, 9 * nc);
-  ALLOC(h->d_px, 9 * nc); ALLOC(h->d_pr, 9 * nc); ALLOC(h->d_pz, 9 * nc); ALLOC(h->d_pp, 9 * nc); ALLOC(h->d_pq, 9 * nc);
+  ALLOC(h->d_px, 9 * nc); ALLOC(h->d_pr, 9 * nc); ALLOC(h->d_pz, 9 * nc); ALLOC(h->d_pp, 9 * nc); ALLOC(h->d_pq, 9 * nc + kPcgMaxBlocks);
   ALLOC(h->d_probe, 9 * nc);
   ALLOC(h->d_part_tile, 4 * nt + 4);
   ALLOC(h->d_part_small, 2 * (size_t)nblk(nc, 64) + 2 * 240 + 512);
