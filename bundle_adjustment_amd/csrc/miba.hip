@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/miba.h"
@@ -749,6 +750,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   int rc = build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->cfg.world_size,
                       po ? atoi(po) : 1);
   if (rc) return fail(h, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", rc);
+  PlanLap lap;
   h->n_cam = p->n_cam;
   h->n_valid_global = P.n_valid;
   h->pcg_nb = std::min(nblk(p->n_cam, kPcgCams), kPcgMaxBlocks);
@@ -786,15 +788,17 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   }
   // observations in chunk-SoA order, point ranges
   std::vector<double> oxy((size_t)(h->n_slots ? h->n_slots : 1) * 2, 0.0);
+  plan_parallel_for(h->n_slots, [&](int64_t a, int64_t b) {
+    for (int64_t s = a; s < b; ++s) {
+      const int64_t o = P.slot_orig[h->slot_base + s];
+      if (o < 0) continue;
+      const size_t chunk = (size_t)(s / kChunk), lane = (size_t)(s % kChunk);
+      oxy[chunk * 2 * kChunk + lane] = p->obs_xy[2 * o];
+      oxy[chunk * 2 * kChunk + kChunk + lane] = p->obs_xy[2 * o + 1];
+    }
+  });
   h->n_obs_local = 0;
-  for (int64_t s = 0; s < h->n_slots; ++s) {
-    const int64_t o = P.slot_orig[h->slot_base + s];
-    if (o < 0) continue;
-    const size_t chunk = (size_t)(s / kChunk), lane = (size_t)(s % kChunk);
-    oxy[chunk * 2 * kChunk + lane] = p->obs_xy[2 * o];
-    oxy[chunk * 2 * kChunk + kChunk + lane] = p->obs_xy[2 * o + 1];
-    h->n_obs_local++;
-  }
+  for (int32_t q = 0; q < h->n_pt; ++q) h->n_obs_local += P.pt_count[h->pt_base + q];
   std::vector<int2> wlv((size_t)(h->n_slots / kWave) + 1);
   {
     // per wavelet: {first (local) point of the enclosing 256-slot chunk, longest point run in the wavelet}
@@ -811,25 +815,46 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     pt_rng[q].x = P.pt_first[h->pt_base + q] - (int32_t)h->slot_base;
     pt_rng[q].y = P.pt_count[h->pt_base + q];
   }
+  lap("local arrays (oxy, ranges)");
   // camera-major copy of the local observations, cut into segments of at most kSegObs observations of one camera
   std::vector<int4> segv;
   std::vector<int32_t> cmo_pt((size_t)(h->n_obs_local ? h->n_obs_local : 1)), cam_seg_off((size_t)p->n_cam + 1, 0);
   std::vector<double2> cmo_xy((size_t)(h->n_obs_local ? h->n_obs_local : 1));
   {
-    std::vector<int64_t> coff((size_t)p->n_cam + 1, 0);
-    for (int64_t s = 0; s < h->n_slots; ++s)
-      if (P.slot_orig[h->slot_base + s] >= 0) coff[(size_t)P.ocam[h->slot_base + s] + 1]++;
-    for (int c = 0; c < p->n_cam; ++c) coff[c + 1] += coff[c];
-    std::vector<int64_t> cur(coff.begin(), coff.end() - 1);
-    for (int32_t q = 0; q < h->n_pt; ++q) {   // ascending point order inside every camera
-      const int64_t s0 = pt_rng[q].x;
-      for (int64_t s = s0; s < s0 + pt_rng[q].y; ++s) {
-        const int64_t o = P.slot_orig[h->slot_base + s];
-        const int64_t d = cur[P.ocam[h->slot_base + s]]++;
-        cmo_pt[d] = q;
-        cmo_xy[d] = make_double2(p->obs_xy[2 * o], p->obs_xy[2 * o + 1]);
-      }
+    // stable counting sort of the local observations by camera, the points cut into R ranges that are counted
+    // and scattered by R threads (ascending point order inside every camera is kept)
+    const int R = 16;
+    const size_t ncam = (size_t)p->n_cam;
+    std::vector<int64_t> cnt((size_t)R * ncam, 0), coff(ncam + 1, 0);
+    auto range = [&](int r) { return std::make_pair((int64_t)h->n_pt * r / R, (int64_t)h->n_pt * (r + 1) / R); };
+    auto for_ranges = [&](auto fn) {
+      std::vector<std::thread> th;
+      for (int r = 1; r < R; ++r) th.emplace_back(fn, r);
+      fn(0);
+      for (auto& x : th) x.join();
+    };
+    for_ranges([&](int r) {
+      int64_t* c = cnt.data() + (size_t)r * ncam;
+      const auto qr = range(r);
+      for (int64_t q = qr.first; q < qr.second; ++q)
+        for (int64_t s = pt_rng[q].x; s < (int64_t)pt_rng[q].x + pt_rng[q].y; ++s) c[P.ocam[h->slot_base + s]]++;
+    });
+    for (size_t c = 0; c < ncam; ++c) {
+      int64_t acc = coff[c];
+      for (int r = 0; r < R; ++r) { const int64_t v = cnt[(size_t)r * ncam + c]; cnt[(size_t)r * ncam + c] = acc; acc += v; }
+      coff[c + 1] = acc;
     }
+    for_ranges([&](int r) {
+      int64_t* cur = cnt.data() + (size_t)r * ncam;
+      const auto qr = range(r);
+      for (int64_t q = qr.first; q < qr.second; ++q)
+        for (int64_t s = pt_rng[q].x; s < (int64_t)pt_rng[q].x + pt_rng[q].y; ++s) {
+          const int64_t o = P.slot_orig[h->slot_base + s];
+          const int64_t d = cur[P.ocam[h->slot_base + s]]++;
+          cmo_pt[d] = (int32_t)q;
+          cmo_xy[d] = make_double2(p->obs_xy[2 * o], p->obs_xy[2 * o + 1]);
+        }
+    });
     for (int c = 0; c < p->n_cam; ++c) {
       cam_seg_off[c] = (int32_t)segv.size();
       for (int64_t a = coff[c]; a < coff[c + 1]; a += kSegObs)
@@ -838,6 +863,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     cam_seg_off[p->n_cam] = (int32_t)segv.size();
     h->n_seg = (int32_t)segv.size();
   }
+  lap("camera-major copy");
 #define ALLOC(ptr, n)                        \
   do {                                       \
     rc = dev_alloc(h, &(ptr), (size_t)(n));  \
@@ -892,6 +918,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   UP(h->d_cam_seg_off, cam_seg_off.data(), nc + 1);
 #undef ALLOC
 #undef UP
+  lap("alloc + upload");
   hipLaunchKernelGGL(k_fill, dim3(nblk(9 * nc, 256)), dim3(256), 0, h->st, 9 * nc, 1.0, h->d_cfree);   // all blocks free
   HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
   HIPCHK(h, hipMemsetAsync(h->d_max, 0, S_COUNT * sizeof(double), h->st));

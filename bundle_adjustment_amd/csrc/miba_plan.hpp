@@ -15,9 +15,39 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <chrono>
+#include <cstdio>
+#include <thread>
 #include <vector>
 
 namespace miba {
+
+// fn(begin, end) over [0, n) on up to 16 host threads (MIBA_PLAN_THREADS overrides); ranges are disjoint
+template <typename F>
+inline void plan_parallel_for(int64_t n, F fn) {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char* e = getenv("MIBA_PLAN_THREADS")) t = (unsigned)atoi(e);
+  if (t < 1) t = 1;
+  if (t > 16) t = 16;
+  if (n < (1 << 16) || t == 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  for (unsigned k = 1; k < t; ++k) th.emplace_back(fn, n * k / t, n * (k + 1) / t);
+  fn(0, n / t);
+  for (auto& x : th) x.join();
+}
+
+// MIBA_DEBUG_PLAN=1: phase times of the host tiler on stderr
+struct PlanLap {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  bool on = getenv("MIBA_DEBUG_PLAN") != nullptr;
+  void operator()(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[miba plan] %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 
 constexpr int kChunk = 256;        // observation slots per chunk = threads per block
 constexpr int kWave = 64;          // a point never straddles a 64-slot wavelet (one wavefront)
@@ -67,6 +97,7 @@ struct Plan {
 inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const int32_t* obs_cam,
                       const int32_t* obs_pt, const double* obs_xy, const double* X, int world_size,
                       int point_order) {
+  PlanLap lap;
   P = Plan();
   P.n_cam = n_cam; P.n_pt_in = n_pt; P.n_obs_in = n_obs;
   if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || world_size < 1) return -1;
@@ -90,14 +121,22 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     P.cam_active[c] = 1;
     P.n_valid++;
   }
+  lap("filter");
   P.n_active_cam = 0;
   for (int c = 0; c < n_cam; ++c) P.n_active_cam += P.cam_active[c];
   // --- order active points
   P.pt_orig.reserve(n_pt);
   for (int32_t p = 0; p < n_pt; ++p) if (cnt[p] > 0) P.pt_orig.push_back(p);
-  if (point_order == 1)
-    std::stable_sort(P.pt_orig.begin(), P.pt_orig.end(),
-                     [&](int32_t a, int32_t b) { return mincam[a] < mincam[b]; });
+  if (point_order == 1) {
+    // stable counting sort by smallest camera index
+    std::vector<int64_t> first(n_cam + 1, 0);
+    for (int32_t p : P.pt_orig) first[mincam[p] + 1]++;
+    for (int c = 0; c < n_cam; ++c) first[c + 1] += first[c];
+    std::vector<int32_t> sorted(P.pt_orig.size());
+    for (int32_t p : P.pt_orig) sorted[first[mincam[p]]++] = p;
+    P.pt_orig.swap(sorted);
+  }
+  lap("order points");
   const int32_t n_act = (int32_t)P.pt_orig.size();
   std::vector<int32_t> sorted_of(n_pt, -1);
   for (int32_t s = 0; s < n_act; ++s) sorted_of[P.pt_orig[s]] = s;
@@ -110,9 +149,12 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     for (int64_t i = 0; i < n_obs; ++i)
       if (ok[i]) obs_sorted[cur[sorted_of[obs_pt[i]]]++] = i;
   }
-  for (int32_t s = 0; s < n_act; ++s)
-    std::stable_sort(obs_sorted.begin() + off[s], obs_sorted.begin() + off[s + 1],
-                     [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
+  plan_parallel_for(n_act, [&](int64_t s0, int64_t s1) {
+    for (int64_t s = s0; s < s1; ++s)
+      std::stable_sort(obs_sorted.begin() + off[s], obs_sorted.begin() + off[s + 1],
+                       [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
+  });
+  lap("bucket + per-point sort");
   // --- tiling, phase 1: cut the point sequence into tiles.  A tile holds whole points, at most kMaxCamSlots
   // distinct cameras and about max_chunks chunks of observations; a giant point (more observations than a
   // wavefront) is a tile of its own.
@@ -158,6 +200,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     }
     close(n_act);
   }
+  lap("phase 1 (tile spans)");
   // --- phase 2: lay every tile out.  Inside a tile the point order is free, so its points are packed
   // first-fit-decreasing into 64-slot wavelets (a point never straddles a wavelet): little padding, and points
   // of similar length share a wavelet, which keeps the segmented scans of the kernels short.  Points are
@@ -264,6 +307,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     P.tiles.push_back(T);
     if (slots >= (int64_t)INT32_MAX - kChunk) return -6;
   }
+  lap("phase 2 (layout)");
   if (slots >= (int64_t)INT32_MAX - kChunk) return -6;   // slot indices are int32 on the device
   P.pt_orig.swap(new_orig);
   P.n_slots = slots;
@@ -284,6 +328,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     }
     P.shard_tile[world_size] = nt;
   }
+  lap("wavelets + shards");
   return 0;
 }
 
