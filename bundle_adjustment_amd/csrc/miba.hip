@@ -665,7 +665,8 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
   // MIBA_TEST_NO_COMM=1 (tests only): a rank of a multi-rank world without a communicator, so that its
   // un-reduced partial sums can be inspected on a single GPU; solves are meaningless in this mode
   const char* nocomm = getenv("MIBA_TEST_NO_COMM");
-  if ((cfg->world_size > 1 && !(nocomm && nocomm[0] == '1')) || (force && force[0] == '1')) {
+  const bool no_comm = nocomm && nocomm[0] == '1';
+  if (!no_comm && (cfg->world_size > 1 || (force && force[0] == '1'))) {
     ncclUniqueId id;
     if (cfg->comm_unique_id) memcpy(&id, cfg->comm_unique_id, sizeof(id));
     else if (cfg->world_size == 1) {

@@ -51,7 +51,8 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
 }
-// sum over a 256-thread block; result valid in every thread; s4 = 4 doubles of LDS
+// sum over a 256-thread block (exactly four wavefronts: a smaller block would read unwritten LDS slots);
+// result valid in every thread; s4 = 4 doubles of LDS
 __device__ __forceinline__ double block_sum(double v, double* s4) {
   v = wave_sum(v);
   __syncthreads();
@@ -827,7 +828,6 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const ui
                              double* __restrict__ Minv /*[n][81]*/, double* __restrict__ Dc2 /*[n][9]*/,
                              double* __restrict__ rhs /*[n][9]*/, double* __restrict__ partial /*[nblk][2]*/,
                              Ctl* __restrict__ ctl) {
-  __shared__ double s4[4];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   double gmax = 0.0, g2 = 0.0;
   if (c < n_cam) {
@@ -883,8 +883,9 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const ui
       }
     }
   }
-  const double m = block_max(gmax, s4);
-  const double s = block_sum(g2, s4);
+  // launched with 64-thread blocks (one wavefront): wave reductions, NOT the 256-thread block_sum / block_max
+  const double m = wave_max(gmax);
+  const double s = wave_sum(g2);
   if (threadIdx.x == 0) { partial[2 * (size_t)blockIdx.x] = m; partial[2 * (size_t)blockIdx.x + 1] = s; }
 }
 
