@@ -20,6 +20,7 @@
 #include "../../include/miba.h"
 #include "miba_kernels.hpp"
 #include "miba_mf.hpp"
+#include "miba_dense.hpp"
 #include "miba_plan.hpp"
 
 using namespace miba;
@@ -83,6 +84,12 @@ struct miba_handle_s {
   double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
   double *d_slab64 = nullptr, *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
   double *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pq = nullptr, *d_probe = nullptr;
+  // exact reduced solve (miba_dense.hpp), allocated on first use: dense S [N + 64][N], factors of its diagonal blocks, pivot flag
+  double *d_S = nullptr, *d_Linv = nullptr;
+  int32_t* d_dflag = nullptr;
+  int dense_N = 0;
+  int4* d_dseg = nullptr; int32_t* d_dpts = nullptr; int32_t n_dseg = 0;   // planned assembly: block segments, their points
+  bool dense_planned = false;
   double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
   double *d_sum = nullptr, *d_max = nullptr;   // [S_COUNT] each
   Ctl* d_ctl = nullptr;
@@ -478,6 +485,160 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
   *n_it = h->h_ctl->n_it;
   *status = h->h_ctl->status;
   return MIBA_OK;
+}
+
+
+// ---- exact reduced solve (non-iterative linear_solver_type, few cameras) --------------------
+// Used when the options ask for a factorisation-based solver, the matrix-free kernels are active and
+// N = 9 n_cam (rounded up to 64) <= kDenseMaxN; MIBA_DENSE=0 keeps the PCG-to-eta_exact stand-in.
+bool dense_wanted(miba_handle h, const miba_options* o) {
+  if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR || !h->use_mf) return false;
+  const char* e = getenv("MIBA_DENSE");
+  if (e && atoi(e) == 0) return false;
+  const size_t N = (9 * (size_t)h->n_cam + kNB - 1) / kNB * kNB;
+  return N <= (size_t)kDenseMaxN;
+}
+
+
+// Pair plan of the explicit Schur complement: every (observation a, observation b) of one point with
+// camera(a) > camera(b), or the same camera (both orders and a == b: duplicates square correctly), is one
+// instance of block (camera(a), camera(b)); instances are counting-sorted by block and cut into segments.
+// Skipped (k_dense_pairs' atomics take over) beyond kDensePlanMax instances or with MIBA_DENSE_PLAN=0.
+constexpr int64_t kDensePlanMax = (int64_t)1 << 28;
+int dense_plan(miba_handle h) {
+  h->dense_planned = false;
+  if (const char* e = getenv("MIBA_DENSE_PLAN")) if (atoi(e) == 0) return MIBA_OK;
+  const Plan& P = h->plan;
+  const int32_t nc = h->n_cam;
+  if (nc > 4096) return MIBA_OK;
+  const size_t nkey = (size_t)nc * (nc + 1) / 2;
+  // the host copy of the per-slot camera ids was released after the upload: read the shard's back
+  std::vector<int32_t> ocam((size_t)(h->n_slots ? h->n_slots : 1));
+  if (h->n_slots) HIPCHK(h, hipMemcpy(ocam.data(), h->d_ocam, (size_t)h->n_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<int64_t> first(nkey + 1, 0);
+  auto key_of = [](int32_t ci, int32_t cj) { return (size_t)ci * (ci + 1) / 2 + cj; };
+  int64_t total = 0;
+  for (int32_t q = 0; q < h->n_pt; ++q) {
+    const int32_t* c = ocam.data() + (P.pt_first[h->pt_base + q] - h->slot_base);
+    const int32_t L = P.pt_count[h->pt_base + q];
+    for (int32_t a = 0; a < L; ++a)
+      for (int32_t b = 0; b < L; ++b)
+        if (c[a] >= c[b]) { first[key_of(c[a], c[b]) + 1]++; ++total; }
+    if (total > kDensePlanMax) return MIBA_OK;
+  }
+  for (size_t k = 0; k < nkey; ++k) first[k + 1] += first[k];
+  std::vector<int32_t> pts((size_t)(total ? total : 1));
+  {
+    std::vector<int64_t> cur(first.begin(), first.end() - 1);
+    for (int32_t q = 0; q < h->n_pt; ++q) {
+      const int32_t* c = ocam.data() + (P.pt_first[h->pt_base + q] - h->slot_base);
+      const int32_t L = P.pt_count[h->pt_base + q];
+      for (int32_t a = 0; a < L; ++a)
+        for (int32_t b = 0; b < L; ++b)
+          if (c[a] >= c[b]) pts[(size_t)cur[key_of(c[a], c[b])]++] = q;
+    }
+  }
+  std::vector<int4> segs;
+  for (int32_t ci = 0; ci < nc; ++ci)
+    for (int32_t cj = 0; cj <= ci; ++cj) {
+      const size_t k = key_of(ci, cj);
+      const int64_t n = first[k + 1] - first[k];
+      for (int64_t o = 0; o < n; o += kDenseSeg)
+        segs.push_back(make_int4(ci | (cj << 12), (int)(first[k] + o), (int)std::min<int64_t>(kDenseSeg, n - o), n > kDenseSeg ? 1 : 0));
+    }
+  int rc = dev_alloc(h, &h->d_dseg, segs.size());
+  if (rc) return rc;
+  rc = dev_alloc(h, &h->d_dpts, pts.size());
+  if (rc) return rc;
+  if (!segs.empty()) HIPCHK(h, hipMemcpy(h->d_dseg, segs.data(), segs.size() * sizeof(int4), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_dpts, pts.data(), pts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->n_dseg = (int32_t)segs.size();
+  h->dense_planned = true;
+  return MIBA_OK;
+}
+
+int ensure_dense(miba_handle h) {
+  if (h->d_S) return MIBA_OK;
+  const size_t N = (9 * (size_t)h->n_cam + kNB - 1) / kNB * kNB;
+  int rc = dev_alloc(h, &h->d_S, (N + kNB) * N);   // 64 extra rows: row N carries the right-hand side
+  if (rc) return rc;
+  rc = dev_alloc(h, &h->d_Linv, (N / kNB) * (size_t)kLdiag);
+  if (rc) return rc;
+  rc = dev_alloc(h, &h->d_dflag, 1);
+  if (rc) return rc;
+  h->dense_N = (int)N;
+  return dense_plan(h);
+}
+
+// S (lower triangle, row-major [N][N]) of the current Schur init: point pairs, all-reduce, block diagonal
+int dense_assemble(miba_handle h) {
+  int rc = ensure_dense(h);
+  if (rc) return rc;
+  const int N = h->dense_N;
+  HIPCHK(h, hipMemsetAsync(h->d_S, 0, ((size_t)N + kNB) * N * sizeof(double), h->st));
+  if (h->dense_planned) {
+    if (h->n_dseg)
+      hipLaunchKernelGGL(k_dense_blocks, dim3(nblk(h->n_dseg, 4)), dim3(256), 0, h->st, h->n_dseg, h->d_dseg, h->d_dpts, h->d_ct, h->d_cm,
+                         h->d_sc, h->d_ptrec, h->d_S, N);
+  } else if (h->n_tiles) {
+    hipLaunchKernelGGL(k_dense_pairs, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_tile_cams,
+                       h->d_ct, h->d_cm, h->d_sc, h->d_ptrec, h->d_S, N);
+    if (h->n_giant)
+      hipLaunchKernelGGL(k_dense_pairs_giant, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
+                         h->d_idx, h->d_ocam, h->d_ct, h->d_cm, h->d_sc, h->d_ptrec, h->d_S, N);
+  }
+  HIPCHK(h, hipGetLastError());
+  rc = allreduce(h, h->d_S, (size_t)N * N, ncclSum);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_dense_diag, dim3(nblk(81 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, h->d_camacc, h->d_Dc2, h->d_S, N);
+  HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
+// blocked Cholesky of the lower triangle of A ([N + 64][N], N a multiple of 64, rows N.. zero) and the solve
+// A x = b; x receives the first n_out entries.  *status: 0 ok, 2 a pivot was not positive (A is not SPD).
+int dense_factor_solve(miba_handle h, double* A, int N, double* Ldiag, const double* b, int n_b, double* x, int n_out,
+                       int32_t* d_flag, int* status) {
+  HIPCHK(h, hipMemsetAsync(d_flag, 0, sizeof(int32_t), h->st));
+  hipLaunchKernelGGL(k_dense_rhs, dim3(nblk(N, 256)), dim3(256), 0, h->st, n_b, N, b, A);
+  const int nb = N / kNB;
+  const int NR = N + kNB;
+  for (int k = 0; k < nb; ++k) {
+    const int k0 = k * kNB;
+    const int below = nb - 1 - k;                        // 64-column tiles to the right
+    hipLaunchKernelGGL(k_chol_panel, dim3((below + 1 + 3) / 4), dim3(256), 0, h->st, A, N, NR, k0, Ldiag + (size_t)k * kLdiag, (int*)d_flag);
+    if (below > 0) hipLaunchKernelGGL(k_chol_update, dim3(below, below + 1), dim3(256), 0, h->st, A, N, k0);
+  }
+  for (int k = nb - 1; k >= 0; --k) {
+    const int k0 = k * kNB;
+    hipLaunchKernelGGL(k_chol_bwd, dim3(nblk((size_t)k0, 256)), dim3(256), 0, h->st, A, N, k0, (const double*)(Ldiag + (size_t)k * kLdiag), x,
+                       n_out);
+  }
+  HIPCHK(h, hipGetLastError());
+  int32_t flag = 0;
+  HIPCHK(h, hipMemcpyAsync(&flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->st));
+  if (h->d_ctl) HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));   // Schur-init failure flag
+  int rc = sync_stream(h);
+  if (rc) return rc;
+  *status = flag ? 2 : 0;
+  return MIBA_OK;
+}
+
+// exact solution of S y = rhs into d_px
+int dense_solve(miba_handle h, int* status) {
+  int rc = dense_assemble(h);
+  if (rc) return rc;
+  return dense_factor_solve(h, h->d_S, h->dense_N, h->d_Linv, h->d_rhs, 9 * h->n_cam, h->d_px, 9 * h->n_cam, h->d_dflag, status);
+}
+
+// the linear solve of one LM iteration: exact factorisation where it applies, PCG otherwise
+int linear_solve(miba_handle h, const miba_options* o, int* n_it, int* status) {
+  if (dense_wanted(h, o)) {
+    *n_it = 1;
+    return dense_solve(h, status);
+  }
+  const double q_tol = (o->linear_solver_type == MIBA_ITERATIVE_SCHUR) ? o->eta : o->eta_exact;
+  return pcg_solve(h, q_tol, o->min_linear_solver_iterations, o->max_linear_solver_iterations, o->pcg_check_every, n_it, status);
 }
 
 // back-substitution, candidate state, model cost change, step / candidate norms
@@ -890,6 +1051,8 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_cfree, 9 * nc); ALLOC(h->d_slabB, (size_t)kK2W * segv.size());
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
+  h->d_S = nullptr; h->d_Linv = nullptr; h->d_dflag = nullptr; h->dense_N = 0;
+  h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false;
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
   // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
   ALLOC(h->d_slab64, (!h->use_mf || h->k2_onepass) ? (size_t)kK2W * n_rows : (size_t)1); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
@@ -1091,8 +1254,7 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
   if (rc) return rc;
   const size_t n = 9 * (size_t)h->n_cam;
   int it = 0, st = 0;
-  const double q_tol = (opt->linear_solver_type == MIBA_ITERATIVE_SCHUR) ? opt->eta : opt->eta_exact;
-  rc = pcg_solve(h, q_tol, opt->min_linear_solver_iterations, opt->max_linear_solver_iterations, opt->pcg_check_every, &it, &st);
+  rc = linear_solve(h, opt, &it, &st);
   if (rc) return rc;
   if (n_cg) *n_cg = it;
   rc = backsub_and_candidate(h);
@@ -1122,6 +1284,57 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
     HIPCHK(h, hipMemcpy(s_probe, h->d_pq, n * sizeof(double), hipMemcpyDeviceToHost));
   }
   return MIBA_OK;
+}
+
+int miba_get_reduced_system(miba_handle h, double* S_out) {
+  if (!h || !h->has_problem || !S_out) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->jac_valid) return fail(h, MIBA_ERR_INVALID, "call miba_linear_step first (Schur blocks not set up)");
+  if (!h->use_mf) return fail(h, MIBA_ERR_INVALID, "the explicit reduced system needs the matrix-free kernels (MIBA_MF=0 is set)");
+  const size_t n = 9 * (size_t)h->n_cam;
+  if ((n + kNB - 1) / kNB * kNB > (size_t)kDenseMaxN) return fail(h, MIBA_ERR_INVALID, "too many cameras for the dense reduced system (%d > %d rows)", (int)n, kDenseMaxN);
+  int rc = dense_assemble(h);
+  if (rc) return rc;
+  rc = sync_stream(h);
+  if (rc) return rc;
+  const size_t N = (size_t)h->dense_N;
+  HIPCHK(h, hipMemcpy2D(S_out, n * sizeof(double), h->d_S, N * sizeof(double), n * sizeof(double), n, hipMemcpyDeviceToHost));
+  for (size_t r = 0; r < n; ++r)
+    for (size_t c = r + 1; c < n; ++c) S_out[r * n + c] = S_out[c * n + r];
+  return MIBA_OK;
+}
+
+int miba_dense_spd_solve(miba_handle h, int32_t n, const double* A, const double* b, double* x, int32_t* status) {
+  if (!h || n < 1 || !A || !b || !x || !status) return fail(h, MIBA_ERR_INVALID, "bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t N = ((size_t)n + kNB - 1) / kNB * kNB;
+  if (N > (size_t)kDenseMaxN) return fail(h, MIBA_ERR_INVALID, "n = %d exceeds the dense limit %d", n, kDenseMaxN);
+  double *dA = nullptr, *dL = nullptr, *dv = nullptr;   // dv: b, x
+  int32_t* df = nullptr;
+  auto cleanup = [&]() { (void)hipFree(dA); (void)hipFree(dL); (void)hipFree(dv); (void)hipFree(df); };
+  hipError_t e = hipMalloc(&dA, (N + kNB) * N * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dL, (N / kNB) * (size_t)kLdiag * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dv, 2 * N * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&df, sizeof(int32_t));
+  if (e != hipSuccess) { cleanup(); return fail(h, MIBA_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+  // identity on the padding, the caller's matrix in the leading n x n, zero rows below
+  std::vector<double> pad((N + kNB) * N, 0.0);
+  for (size_t r = 0; r < N; ++r) {
+    if (r < (size_t)n) memcpy(&pad[r * N], A + r * (size_t)n, (size_t)n * sizeof(double));
+    else pad[r * N + r] = 1.0;
+  }
+  e = hipMemcpy(dA, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { cleanup(); return fail(h, MIBA_ERR_HIP, "upload failed: %s", hipGetErrorString(e)); }
+  int st = 0;
+  int rc = dense_factor_solve(h, dA, (int)N, dL, dv, n, dv + N, n, df, &st);
+  if (rc == MIBA_OK) {
+    e = hipMemcpy(x, dv + N, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(h, MIBA_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+  }
+  cleanup();
+  *status = st;
+  return rc;
 }
 
 int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* avg_ms) {
@@ -1168,7 +1381,6 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
   S.num_active_cameras = h->plan.n_active_cam;
   S.num_active_points = (int32_t)h->plan.pt_orig.size();
   snprintf(S.message, sizeof(S.message), "Maximum number of iterations reached.");
-  const double q_tol = (o.linear_solver_type == MIBA_ITERATIVE_SCHUR) ? o.eta : o.eta_exact;
   int rc;
 
   // best-state buffers: d_cam_cand / d_Xc double as candidates, so keep the best state on the host side of
@@ -1250,7 +1462,7 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
     }
     schur_ready = false;
     int n_cg = 0, cg_status = 0;
-    rc = pcg_solve(h, q_tol, o.min_linear_solver_iterations, o.max_linear_solver_iterations, o.pcg_check_every, &n_cg, &cg_status);
+    rc = linear_solve(h, &o, &n_cg, &cg_status);
     if (rc) return rc;
     it.linear_solver_iterations = n_cg;
     S.num_linear_solver_iterations += n_cg;

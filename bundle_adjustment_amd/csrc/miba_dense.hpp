@@ -1,0 +1,409 @@
+// miba_dense.hpp — exact solve of the reduced camera system for problems with few cameras
+// (what Ceres does for DENSE_SCHUR / SPARSE_SCHUR / *_NORMAL_CHOLESKY, the solver
+// type the reference app asks for at app/main.cpp:19, reaches through src/BundleAdjustment.cpp:20,109).
+//
+//   S = B - sum_p G_p' W_p G_p,   G = E' F_s (3 x 9 per observation),  W_p = sp C_p^-1 sp (point record),
+//   B = F_s'F_s + D_c^2 per camera (the block diagonal K2 has already reduced),
+// the same operator the matrix-free product applies, assembled densely (row-major, N = 9 n_cam rounded
+// up to 64, lower triangle), factored by a blocked right-looking Cholesky (diagonal blocks in the registers of
+// one wave, trailing update on the fp64 matrix cores, v_mfma_f64_16x16x4_f64) that carries the forward
+// substitution along, then a blocked backward substitution.
+#pragma once
+
+#include "miba_mf.hpp"
+
+namespace miba {
+
+constexpr int kNB = 64;             // Cholesky block
+constexpr int kDenseMaxN = 18432;   // 2048 cameras: S is 2.7 GB
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// G = E' F_s (3x9, row a = point coordinate) of one observation and T = W G
+__device__ __forceinline__ void dense_obs_G(const double* cd, const double* s /*[9] camera scale*/, double x0, double x1, double x2,
+                                            double* G) {
+  double F[18], E[6], r0, r1;
+  mf_blocks(cd, x0, x1, x2, 0.0, 0.0, F, E, r0, r1);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double f0 = F[k] * s[k], f1 = F[9 + k] * s[k];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) G[9 * a + k] = E[a] * f0 + E[3 + a] * f1;
+  }
+}
+
+__device__ __forceinline__ void dense_WG(const double* W /*00 10 11 20 21 22*/, const double* G, double* T) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    T[k] = W[0] * G[k] + W[1] * G[9 + k] + W[3] * G[18 + k];
+    T[9 + k] = W[1] * G[k] + W[2] * G[9 + k] + W[4] * G[18 + k];
+    T[18 + k] = W[3] * G[k] + W[4] * G[9 + k] + W[5] * G[18 + k];
+  }
+}
+
+// S[cam_i block row][cam_j block column] -= T_i' G_j
+__device__ __forceinline__ void dense_sub_block(double* __restrict__ S, int N, int cam_i, int cam_j, const double* T, const double* Gj) {
+  double* dst = S + (size_t)(9 * cam_i) * N + 9 * cam_j;
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      const double v = -(T[a] * Gj[b] + T[9 + a] * Gj[9 + b] + T[18 + a] * Gj[18 + b]);
+      atomicAdd(dst + (size_t)a * N + b, v);
+    }
+}
+
+// K5: point side of the explicit Schur complement.  Wavelet layout of K3: a wave owns whole points; lane i
+// visits the other observations of its point by rotating through the run (lane shuffles) and handles the
+// pairs whose camera index is not larger than its own, so only the lower block triangle is written.
+__global__ __launch_bounds__(256) void k_dense_pairs(const Tile* __restrict__ tiles, const int32_t* __restrict__ idx,
+                                                     const int2* __restrict__ wl, const int32_t* __restrict__ tile_cams,
+                                                     const double* __restrict__ ct, const double* __restrict__ cm,
+                                                     const double* __restrict__ sc, const double* __restrict__ ptrec,
+                                                     double* __restrict__ S, int N) {
+  __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
+  __shared__ double s_sc[kMaxCamSlots * 9];
+  __shared__ int s_id[kMaxCamSlots];
+  const Tile t = tiles[blockIdx.x];
+  if (t.giant) return;
+  const int tid = threadIdx.x;
+  if (tid < t.ncs) {
+    const int cam = tile_cams[t.cam0 + tid];
+    mf_stage_cam_init(s_cam + kCamLds * tid, cam, ct, cm);
+    s_id[tid] = cam;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_sc[9 * tid + k] = sc[9 * (size_t)cam + k];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nwl = t.nslot / kWave;
+  for (int q = wv; q < nwl; q += 4) {
+    const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
+    const int32_t w = idx[slot];
+    const int2 wq = wl[(t.slot0 >> 6) + q];
+    const int maxrun = wq.y;
+    const bool valid = w >= 0;
+    const int cs = valid ? ((w >> 8) & 0xFF) : 0, pl = valid ? (w & 0xFF) : 0;
+    const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
+    const double* rp = ptrec + (size_t)kPtRec * (size_t)(wq.x + pl);
+    double G[27], T[27];
+    double cd[kCamLds];
+    mf_read_cam(cd, s_cam, cs);
+    dense_obs_G(cd, s_sc + 9 * cs, rp[0], rp[1], rp[2], G);
+    if (!valid) {
+#pragma unroll
+      for (int m = 0; m < 27; ++m) G[m] = 0.0;
+    }
+    dense_WG(rp + 6, G, T);
+    const int cam = valid ? s_id[cs] : -1;
+    for (int d = 0; d < maxrun; ++d) {
+      int pj = pos + d;
+      if (pj >= cnt) pj -= cnt;
+      const int src = (lane - pos + pj) << 2;
+      double Gj[27];
+#pragma unroll
+      for (int m = 0; m < 27; ++m) Gj[m] = lane_read(G[m], src);
+      const int camj = __builtin_amdgcn_ds_bpermute(src, cam);
+      if (valid && d < cnt && cam >= camj) dense_sub_block(S, N, cam, camj, T, Gj);
+    }
+  }
+}
+
+// giant points (more than 64 observations): the point's chunks against each other through LDS
+__global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                           const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                           const int32_t* __restrict__ ocam, const double* __restrict__ ct,
+                                                           const double* __restrict__ cm, const double* __restrict__ sc,
+                                                           const double* __restrict__ ptrec, double* __restrict__ S, int N) {
+  __shared__ double s_G[kChunk * 27];
+  __shared__ int s_camj[kChunk];
+  const Tile t = tiles[tile_list[blockIdx.x]];
+  const int tid = threadIdx.x;
+  for (int g = 0; g < t.ngrp; ++g) {
+    const Group Gr = grps[t.grp0 + g];
+    const double* rp = ptrec + (size_t)kPtRec * (size_t)Gr.pt0;
+    const double x0 = rp[0], x1 = rp[1], x2 = rp[2];
+    for (int ci = 0; ci < Gr.nchunk; ++ci) {
+      const size_t slot_i = (size_t)(Gr.chunk0 + ci) * kChunk + tid;
+      const bool valid_i = idx[slot_i] >= 0;
+      const int cam_i = valid_i ? ocam[slot_i] : -1;
+      double T[27];
+      {
+        double Gi[27];
+#pragma unroll
+        for (int m = 0; m < 27; ++m) Gi[m] = 0.0;
+        if (valid_i) {
+          double cd[kCamLds];
+          mf_stage_cam_init(cd, cam_i, ct, cm);
+          dense_obs_G(cd, sc + 9 * (size_t)cam_i, x0, x1, x2, Gi);
+        }
+        dense_WG(rp + 6, Gi, T);
+      }
+      for (int cj = 0; cj < Gr.nchunk; ++cj) {
+        __syncthreads();   // the previous round's readers are done with s_G
+        {
+          const size_t slot_j = (size_t)(Gr.chunk0 + cj) * kChunk + tid;
+          const bool valid_j = idx[slot_j] >= 0;
+          const int cam_j = valid_j ? ocam[slot_j] : -1;
+          double Gj[27];
+#pragma unroll
+          for (int m = 0; m < 27; ++m) Gj[m] = 0.0;
+          if (valid_j) {
+            double cd[kCamLds];
+            mf_stage_cam_init(cd, cam_j, ct, cm);
+            dense_obs_G(cd, sc + 9 * (size_t)cam_j, x0, x1, x2, Gj);
+          }
+#pragma unroll
+          for (int m = 0; m < 27; ++m) s_G[27 * tid + m] = Gj[m];
+          s_camj[tid] = cam_j;
+        }
+        __syncthreads();
+        if (valid_i) {
+          for (int j = 0; j < kChunk; ++j) {
+            const int camj = s_camj[j];
+            if (camj < 0 || cam_i < camj) continue;
+            dense_sub_block(S, N, cam_i, camj, T, s_G + 27 * j);
+          }
+        }
+      }
+    }
+  }
+}
+
+// K5, planned form (the default when the host could list the pair instances): the host sorts every
+// (camera i >= camera j, shared point) instance by block, one wave sums a segment of at most kDenseSeg
+// instances of ONE block with the two camera records in scalar registers and 81 accumulators per lane,
+// then a cross-lane reduction through LDS.  No atomics unless a block was cut into several segments
+// (seg.w = 1), so S is reproducible bit for bit for all but the very largest blocks.
+constexpr int kDenseSeg = 2048;
+__global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci | cj << 12, first, count, atomic}*/,
+                                                      const int32_t* __restrict__ pts, const double* __restrict__ ct,
+                                                      const double* __restrict__ cm, const double* __restrict__ sc,
+                                                      const double* __restrict__ ptrec, double* __restrict__ S, int N) {
+  __shared__ double s_red[4][64 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sg = blockIdx.x * 4 + wv;
+  if (sg >= n_seg) return;
+  const int4 Sg = seg[sg];
+  const int key = __builtin_amdgcn_readfirstlane(Sg.x);
+  const int first = __builtin_amdgcn_readfirstlane(Sg.y), n = __builtin_amdgcn_readfirstlane(Sg.z);
+  const int use_atomic = __builtin_amdgcn_readfirstlane(Sg.w);
+  const int ci = key & 0xFFF, cj = key >> 12;
+  double cdi[kCamLds], cdj[kCamLds], sci[9], scj[9];
+  mf_stage_cam_init(cdi, ci, ct, cm);
+  mf_stage_cam_init(cdj, cj, ct, cm);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { sci[k] = sc[9 * (size_t)ci + k]; scj[k] = sc[9 * (size_t)cj + k]; }
+  double acc[81];
+#pragma unroll
+  for (int k = 0; k < 81; ++k) acc[k] = 0.0;
+  const int32_t* ptp = pts + first;
+  int32_t pt_c = ptp[min(lane, n - 1)];
+  for (int i = lane; i < n; i += 64) {
+    const int32_t pt_n = ptp[min(i + 64, n - 1)];
+    const double* rp = ptrec + (size_t)kPtRec * (size_t)pt_c;
+    double Gi[27], Gj[27], T[27];
+    dense_obs_G(cdi, sci, rp[0], rp[1], rp[2], Gi);
+    if (ci != cj) dense_obs_G(cdj, scj, rp[0], rp[1], rp[2], Gj);
+    else {
+#pragma unroll
+      for (int m = 0; m < 27; ++m) Gj[m] = Gi[m];
+    }
+    dense_WG(rp + 6, Gi, T);
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int b = 0; b < 9; ++b) acc[9 * a + b] = fma(T[a], Gj[b], fma(T[9 + a], Gj[9 + b], fma(T[18 + a], Gj[18 + b], acc[9 * a + b])));
+    pt_c = pt_n;
+  }
+  double* sr = s_red[wv];
+  const int sub = lane / 9, k9 = lane % 9;
+  double* dst = S + (size_t)(9 * ci) * N + 9 * cj;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {   // block row r
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sr[lane * 9 + k] = acc[9 * r + k];
+    __builtin_amdgcn_wave_barrier();
+    double a = 0.0;
+    if (lane < 63)
+      for (int l = sub; l < 64; l += 7) a += sr[l * 9 + k9];
+    double tot = a;
+#pragma unroll
+    for (int s2 = 1; s2 < 7; ++s2) tot += __shfl(a, k9 + 9 * s2, 64);
+    if (lane < 9) {
+      if (use_atomic) atomicAdd(dst + (size_t)r * N + lane, -tot);
+      else dst[(size_t)r * N + lane] = -tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// S += block diagonal B = F_s'F_s + D_c^2 (acc: upper triangle of F_s'F_s per camera), unit diagonal on the padding
+__global__ void k_dense_diag(int n_cam, const double* __restrict__ acc /*[n][64]*/, const double* __restrict__ Dc2,
+                             double* __restrict__ S, int N) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 81 * (size_t)n_cam) {
+    const int c = (int)(i / 81), a = (int)(i % 81) / 9, b = (int)(i % 9);
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    double v = acc[(size_t)kK2W * c + (9 * lo - (lo * (lo - 1)) / 2 + (hi - lo))];
+    if (a == b) v += Dc2[9 * (size_t)c + a];
+    S[(size_t)(9 * c + a) * N + 9 * c + b] += v;
+  }
+  const size_t r = 9 * (size_t)n_cam + i;
+  if (r < (size_t)N) S[r * N + r] = 1.0;
+}
+
+// ---- blocked Cholesky, lower, right-looking --------------------------------------------------
+// The matrix is stored with 64 extra rows: row N holds the right-hand side, so the panel solve and the
+// trailing update carry the forward substitution L y = b along (row N of the factor is y').  Per 64-column
+// step two launches: k_chol_panel (every workgroup factors the 64 x 64 diagonal block itself, in the
+// registers of one wave, then solves its rows of the panel against it) and k_chol_update (fp64 MFMA).
+// The diagonal blocks of S stay as they were; their factors go to Ldiag (per block 64 x 64 + 64 reciprocal
+// diagonal entries) for the backward substitution.
+constexpr int kLdiag = kNB * kNB + kNB;
+constexpr int kLs = kNB + 2;   // LDS row stride of the diagonal factor
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {   // src_lane: wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
+// 1 / sqrt(d): v_rsq_f64 and two Newton steps
+__device__ __forceinline__ double dense_rsqrt(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * fma(-0.5 * d * r, r, 1.5);
+  r = r * fma(-0.5 * d * r, r, 1.5);
+  return r;
+}
+
+// wave 0: Cholesky factor of the diagonal block at k0, lane = row, the row in registers.  Column j of the
+// factor goes to LDS as soon as it exists (Lt[j][r] = L[r][j]) and is read back as wave-uniform operands
+// for the rank-1 update (LDS operations of one wave execute in order: no barrier).  Lr = 1 / diagonal.
+// Returns true if a pivot was not positive.
+__device__ __forceinline__ bool chol_diag_wave(const double* __restrict__ S, int N, int k0, int lane, double* Lt, double* Lr) {
+  double a[kNB];
+  const double* row = S + (size_t)(k0 + lane) * N + k0;
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) a[c] = row[c];
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) a[c] = (c <= lane) ? a[c] : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < kNB; ++j) {
+    double d = lane_bcast(a[j], j);
+    if (!(d > 0.0)) { bad = true; d = 1.0; }
+    const double rd = dense_rsqrt(d);
+    const double l = (lane >= j) ? a[j] * rd : 0.0;
+    Lt[j * kLs + lane] = l;
+    if (lane == 0) Lr[j] = rd;
+#pragma unroll
+    for (int c = j + 1; c < kNB; ++c) a[c] = fma(-l, Lt[j * kLs + c], a[c]);
+    // pin the row after every step: left alone, the compiler turns the unrolled nest into one deferred dot product
+    // per column, keeps every earlier column live for it and spills
+#pragma unroll
+    for (int c = j + 1; c < kNB; ++c) asm volatile("" : "+v"(a[c]));
+  }
+  return bad;
+}
+
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int N, int NR, int k0, double* __restrict__ Ldiag /*[kLdiag]*/,
+                                                    int* __restrict__ flag) {
+  __shared__ __align__(16) double Lt[kNB * kLs];   // Lt[k][c] = L[c][k]
+  __shared__ double Lr[kNB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (wv == 0) {
+    const bool bad = chol_diag_wave(S, N, k0, lane, Lt, Lr);
+    if (bad && blockIdx.x == 0 && lane == 0) *flag = 1;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int i = tid; i < kNB * kNB; i += 256) Ldiag[i] = Lt[(i & 63) * kLs + (i >> 6)];
+    if (tid < kNB) Ldiag[kNB * kNB + tid] = Lr[tid];
+  }
+  // my row of the panel: x L11' = a, right-looking forward substitution (each solved entry updates all the later
+  // ones: independent FMAs), the factor read as wave-uniform LDS operands
+  const int r = k0 + kNB + ((int)blockIdx.x * 4 + wv) * kNB + lane;
+  if (r >= NR) return;
+  double* row = S + (size_t)r * N + k0;
+  double x[kNB];
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) x[c] = row[c];
+#pragma unroll
+  for (int k = 0; k < kNB; ++k) {
+    const double xk = x[k] * Lr[k];
+    x[k] = xk;
+#pragma unroll
+    for (int c = k + 1; c < kNB; ++c) x[c] = fma(-xk, Lt[k * kLs + c], x[c]);
+#pragma unroll
+    for (int c = k + 1; c < kNB; ++c) asm volatile("" : "+v"(x[c]));
+  }
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) row[c] = x[c];
+}
+
+// trailing update A22 -= L21 L21' on the lower block triangle: workgroup = 64 x 64 tile (I >= J), wave = 16 rows,
+// on the fp64 matrix cores (A fragment: lane l holds A[l & 15][4 kk + (l >> 4)]; B[k][n] = L21[col tile row n][k];
+// D: row (l >> 4) + 4 reg, col l & 15).  Row tiles run to NR (the right-hand-side row).
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int N, int k0) {
+  __shared__ double bt[kNB][kNB + 1];
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J > I) return;
+  const int tid = threadIdx.x;
+  const int base = k0 + kNB;
+  const int cj = base + kNB * J;
+  for (int i = tid; i < kNB * kNB; i += 256) bt[i >> 6][i & 63] = S[(size_t)(cj + (i >> 6)) * N + k0 + (i & 63)];
+  __syncthreads();
+  const int l = tid & 63, wv = tid >> 6;
+  const int ar = l & 15, ak = l >> 4;
+  const int ri = base + kNB * I + 16 * wv;
+  double af[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) af[kk] = S[(size_t)(ri + ar) * N + k0 + 4 * kk + ak];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bt[16 * nt + ar][4 * kk + ak], c, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) S[(size_t)(ri + ak + 4 * reg) * N + cj + 16 * nt + ar] -= c[reg];
+  }
+}
+
+// backward step k of L' x = y (y = row N of the factored matrix, updated in place): x_k = L_kk^-T y_k by one wave
+// (lane = unknown, broadcasts of the solved entries), then y_j -= (L_kj)' x_k for the columns to the left
+__global__ __launch_bounds__(256) void k_chol_bwd(double* __restrict__ S, int N, int k0, const double* __restrict__ Ldiag,
+                                                  double* __restrict__ x, int n_out) {
+  __shared__ double Ls[kNB * kLs];
+  __shared__ double xk[kNB];
+  const int tid = threadIdx.x;
+  double* y = S + (size_t)N * N;
+  for (int i = tid; i < kNB * kNB; i += 256) Ls[(i >> 6) * kLs + (i & 63)] = Ldiag[i];
+  __syncthreads();
+  if (tid < kNB) {
+    double yv = y[k0 + tid];
+    const double rdiag = Ldiag[kNB * kNB + tid];
+    double xv = 0.0;
+    for (int k = kNB - 1; k >= 0; --k) {
+      const double xs = lane_bcast(yv * rdiag, k);          // x_k = y_k / L_kk, from lane k
+      if (tid == k) xv = xs;
+      if (tid < k) yv = fma(-Ls[k * kLs + tid], xs, yv);     // y_i -= L[k][i] x_k
+    }
+    xk[tid] = xv;
+    if (blockIdx.x == 0 && k0 + tid < n_out) x[k0 + tid] = xv;
+  }
+  __syncthreads();
+  const int c = (int)blockIdx.x * 256 + tid;
+  if (c < k0) {
+    double sacc = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < kNB; ++r) sacc = fma(S[(size_t)(k0 + r) * N + c], xk[r], sacc);
+    y[c] -= sacc;
+  }
+}
+
+// row N of the matrix = right-hand side (zero on the padding)
+__global__ void k_dense_rhs(int n, int N, const double* __restrict__ v, double* __restrict__ S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) S[(size_t)N * N + i] = (i < n) ? v[i] : 0.0;
+}
+
+}  // namespace miba

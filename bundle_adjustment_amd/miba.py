@@ -22,6 +22,7 @@ EXPORTS = [
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
     "miba_plan_shards", "miba_plan_point_owner", "miba_time_matvec", "miba_set_constant_blocks",
+    "miba_get_reduced_system", "miba_dense_spd_solve",
 ]
 
 
@@ -276,6 +277,23 @@ class Solver:
         ms = C.c_double()
         self._chk(lib().miba_time_matvec(self._h, _dp(v), C.c_int32(reps), C.byref(ms)), "miba_time_matvec")
         return ms.value
+
+    def reduced_system(self):
+        """Explicit Schur complement S (9 n_cam square) of the state prepared by the last linear_step."""
+        n = 9 * self.n_cam
+        S = np.empty((n, n), dtype=np.float64)
+        self._chk(lib().miba_get_reduced_system(self._h, _dp(S)), "miba_get_reduced_system")
+        return S
+
+    def dense_spd_solve(self, A, b):
+        """x = A^-1 b through the device Cholesky; returns (x, status) with status 2 = not positive definite."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        n = A.shape[0]
+        x = np.empty(n, dtype=np.float64)
+        st = C.c_int32()
+        self._chk(lib().miba_dense_spd_solve(self._h, C.c_int32(n), _dp(A), _dp(b), _dp(x), C.byref(st)), "miba_dense_spd_solve")
+        return x, st.value
 
     def kernel_times(self):
         kt = KernelTimes()

@@ -227,6 +227,19 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
                      double* y_pt, double* rhs, const double* probe, double* s_probe,
                      int32_t* n_cg, double* model_cost_change);
 
+/* Exact reduced solve.  A non-iterative options.linear_solver_type (what the reference app
+ * asks for at app/main.cpp:19 and hands to ceres::Solve at src/BundleAdjustment.cpp:20,109) is served by an
+ * explicit dense Schur complement and a blocked Cholesky on the device when 9*n_cam <= 18432 (and the
+ * matrix-free kernels are active); larger problems fall back to PCG run to options.eta_exact.
+ * MIBA_DENSE=0 in the environment forces that fallback.
+ *
+ * miba_get_reduced_system: the matrix S (9*n_cam x 9*n_cam, row-major, symmetric, Jacobi-scaled, LM diagonal
+ * included) of the state prepared by the last miba_linear_step: parity hook for the assembly kernels.
+ * miba_dense_spd_solve: the factorisation alone on a caller-supplied SPD matrix (row-major n x n, lower
+ * triangle read), x = A^-1 b; *status = 0, or 2 when a pivot was not positive. */
+int miba_get_reduced_system(miba_handle h, double* S_out);
+int miba_dense_spd_solve(miba_handle h, int32_t n, const double* A, const double* b, double* x, int32_t* status);
+
 /* Measurement hook: average time of `reps` back-to-back implicit-Schur products S*probe (K3 plus its
  * camera reduction) at the state prepared by the last miba_linear_step. probe has 9*n_cam entries. */
 int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* avg_ms);

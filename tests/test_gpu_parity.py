@@ -111,7 +111,8 @@ def test_linear_step_matches_oracle(oracle, medium):
     rng = np.random.default_rng(5)
     probe = rng.normal(size=(pr["n_cam"], 9))
     s = make_solver(pr, cams0, pts0)
-    opt = miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, eta_exact=1e-14, max_linear_solver_iterations=2000)
+    # PCG run to a tight q-tolerance (the factorisation-based solver types are covered in test_gpu_dense.py)
+    opt = miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, eta=1e-14, max_linear_solver_iterations=2000)
     out = s.linear_step(1e4, opt, probe=probe)
     s.close()
     sc, sp = oracle.jacobi_scale(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
@@ -156,7 +157,7 @@ def test_lm_trajectory_matches_oracle(oracle, medium, solver):
     n_it = 12
     kw = dict(max_num_iterations=n_it, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
     if solver == "exact":
-        # device: tight-tolerance PCG; oracle: explicit dense Schur + Cholesky
+        # device: explicit dense Schur + blocked Cholesky (miba_dense.hpp); oracle: explicit dense Schur + Cholesky
         mo = miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, **kw)
         oo = oracle.default_options(linear_solver=oracle.DENSE_SCHUR, **kw)
         tol = REL_COST
