@@ -1380,6 +1380,7 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
   S.num_residual_blocks = (int32_t)std::min<int64_t>(h->n_valid_global, INT32_MAX);
   S.num_active_cameras = h->plan.n_active_cam;
   S.num_active_points = (int32_t)h->plan.pt_orig.size();
+  S.exact_linear_solver = dense_wanted(h, &o) ? 1 : 0;
   snprintf(S.message, sizeof(S.message), "Maximum number of iterations reached.");
   int rc;
 

@@ -206,7 +206,10 @@ void BundleAdjustment::solve() {
     summary.linear_solver_type_given = options.linear_solver_type;
     summary.linear_solver_used = options.linear_solver_type == ceres::ITERATIVE_SCHUR
                                  ? "ITERATIVE_SCHUR (HIP implicit-Schur PCG, JACOBI preconditioner)"
-                                 : "ITERATIVE_SCHUR (HIP implicit-Schur PCG run to q-tolerance 1e-12 in place of the exact solver)";
+                                 : ms.exact_linear_solver
+                                       ? "DENSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device)"
+                                       : "ITERATIVE_SCHUR (HIP implicit-Schur PCG run to q-tolerance 1e-12 in place of the exact solver: "
+                                         "more than 2048 cameras)";
 
     std::cout << ceres::LinearSolverTypeToString(options.linear_solver_type) << std::endl;
     std::cout << summary.FullReport() << std::endl;

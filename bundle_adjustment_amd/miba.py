@@ -77,7 +77,7 @@ class Summary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("total_time_in_seconds", C.c_double), ("linear_solver_time_in_seconds", C.c_double),
                 ("jacobian_time_in_seconds", C.c_double), ("residual_time_in_seconds", C.c_double),
-                ("message", C.c_char * 128)]
+                ("message", C.c_char * 128), ("exact_linear_solver", C.c_int32), ("reserved", C.c_int32)]
 
 
 class KernelTimes(C.Structure):

@@ -154,6 +154,8 @@ typedef struct {
   double jacobian_time_in_seconds;
   double residual_time_in_seconds;
   char message[128];
+  int32_t exact_linear_solver;      /* 1: the reduced system was factored on the device (dense Schur + Cholesky); 0: PCG */
+  int32_t reserved;
 } miba_summary;
 
 /* per-iteration callback: return one of MIBA_SOLVER_*.  When
