@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--check-every", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--preconditioner", choices=["jacobi", "schur_jacobi"], default="jacobi",
+                    help="PCG preconditioner; jacobi is Ceres' default and what the reference runs with")
     ap.add_argument("--ttt", type=int, default=0, help="also report time-to-cost-tolerance over at most this many LM iterations")
     args = ap.parse_args()
 
@@ -44,6 +46,7 @@ def main():
 
     import torch
     from bundle_adjustment_amd import miba, synth
+    precond = miba.PRECOND_SCHUR_JACOBI if args.preconditioner == "schur_jacobi" else miba.PRECOND_JACOBI
 
     # RCCL prints a version banner on C stdout when the first communicator is made.  The contract is ONE JSON line on
     # stdout, so file descriptor 1 points at stderr until the line is printed.
@@ -103,7 +106,7 @@ def main():
         n_this = warm_left + steps_left
         opt = miba.default_options(max_num_iterations=n_this, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
                                    function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
-                                   pcg_check_every=args.check_every)
+                                   pcg_check_every=args.check_every, preconditioner_type=precond)
         marks = {}
 
         def cb(it, warm=warm_left, n=n_this):
@@ -221,8 +224,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "synthetic BAL-format stand-in for %s: %d cameras / %d points / %d observations, seed %d, "
                                "initial state = ground truth + N(0,%g) on camera rot/trans + N(0,%g) on points; "
-                               "LM + ITERATIVE_SCHUR (implicit Schur, JACOBI preconditioner, eta=%g); %s kernels"
-                               % (args.config, n_cam, n_pt, n_obs, seed, args.sigma_cam, args.sigma_x, args.eta,
+                               "LM + ITERATIVE_SCHUR (implicit Schur, %s preconditioner, eta=%g); %s kernels"
+                               % (args.config, n_cam, n_pt, n_obs, seed, args.sigma_cam, args.sigma_x, args.preconditioner.upper(), args.eta,
                                   "matrix-free" if mf else "stored-Jacobian"),
                    "pcg_iterations_in_timed_steps": n_cg,
                    "successful_steps_in_timed_steps": sum(r["step_is_successful"] for r in timed),
@@ -257,7 +260,7 @@ def main():
         # iteration at this size), reported is the solver time at the first iteration whose cost is <= (1 + 1e-6) C*.
         solver.set_state(cams0, pts0)
         o2 = miba.default_options(max_num_iterations=args.ttt, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
-                                  pcg_check_every=args.check_every)
+                                  pcg_check_every=args.check_every, preconditioner_type=precond)
         its2, summ2 = solver.solve(o2)
         cstar = summ2["final_cost"]
         hit = next(r for r in its2 if r["cost"] <= (1.0 + 1e-6) * cstar)
@@ -272,7 +275,8 @@ def main():
         from oracle import oracle as O
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
         oo = O.default_options(max_num_iterations=args.cpu_iters, linear_solver=O.ITERATIVE_SCHUR, eta=args.eta,
-                               function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0, num_threads=cores)
+                               function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0, num_threads=cores,
+                               preconditioner=O.SCHUR_JACOBI if args.preconditioner == "schur_jacobi" else O.JACOBI)
         _, _, oits, osumm = O.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], oo)
         # compare on the iterations both runs have (the first miba_solve call starts from the same state)
         n_cpu = min(len(oits), len(first_its)) - 1

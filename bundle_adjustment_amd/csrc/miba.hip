@@ -88,6 +88,7 @@ struct miba_handle_s {
   double *d_S = nullptr, *d_Linv = nullptr;
   int32_t* d_dflag = nullptr;
   int dense_N = 0;
+  double* d_camacc2 = nullptr;   // SCHUR_JACOBI: per-camera sum G'WG [n_cam][64], allocated on first use
   int4* d_dseg = nullptr; int32_t* d_dpts = nullptr; int32_t n_dseg = 0;   // planned assembly: block segments, their points
   bool dense_planned = false;
   double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
@@ -327,8 +328,27 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   if (rc) return rc;
   rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
   if (rc) return rc;
+  const double* acc2 = nullptr;
+  if (o->preconditioner_type == MIBA_PRECOND_SCHUR_JACOBI && o->linear_solver_type == MIBA_ITERATIVE_SCHUR) {
+    // block diagonal of S itself: one more camera-major pass for sum G'WG (needs the point records K2 has just written)
+    if (!h->use_mf || h->k2_onepass)
+      return fail(h, MIBA_ERR_INVALID, "preconditioner SCHUR_JACOBI needs the two-pass matrix-free kernels (MIBA_MF=0 or MIBA_K2_ONEPASS=1 is set)");
+    if (!h->d_camacc2) {
+      rc = dev_alloc(h, &h->d_camacc2, (size_t)kK2W * h->n_cam);
+      if (rc) return rc;
+    }
+    if (h->n_seg)
+      hipLaunchKernelGGL(k_mf_schurdiag, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_ct, h->d_cm,
+                         h->d_ptrec, h->d_slabB);
+    hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_seg_off, h->d_slabB, h->d_sc,
+                       h->d_camacc2);
+    HIPCHK(h, hipGetLastError());
+    rc = allreduce(h, h->d_camacc2, (size_t)kK2W * h->n_cam, ncclSum);
+    if (rc) return rc;
+    acc2 = h->d_camacc2;
+  }
   const int nb = nblk(h->n_cam, 64);
-  hipLaunchKernelGGL(k_cam_blocks, dim3(nb), dim3(64), 0, h->st, h->n_cam, h->d_camacc, h->d_cam_active, h->d_sc, inv_r,
+  hipLaunchKernelGGL(k_cam_blocks, dim3(nb), dim3(64), 0, h->st, h->n_cam, h->d_camacc, acc2, h->d_cam_active, h->d_sc, inv_r,
                      o->min_lm_diagonal, o->max_lm_diagonal, h->d_Minv, h->d_Dc2, h->d_rhs, h->d_part_small, h->d_ctl);
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 0, 1, h->d_max + S_GMAX_C);
@@ -1052,7 +1072,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   h->d_S = nullptr; h->d_Linv = nullptr; h->d_dflag = nullptr; h->dense_N = 0;
-  h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false;
+  h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false; h->d_camacc2 = nullptr;
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
   // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
   ALLOC(h->d_slab64, (!h->use_mf || h->k2_onepass) ? (size_t)kK2W * n_rows : (size_t)1); ALLOC(h->d_slab9, 9 * (size_t)n_rows);

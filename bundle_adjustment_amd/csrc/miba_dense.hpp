@@ -238,6 +238,66 @@ __global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __r
   }
 }
 
+// SCHUR_JACOBI preconditioner (ceres::SCHUR_JACOBI): the block diagonal of S itself needs, per camera,
+// sum over its observations of G' W G (G = E'F unscaled here, the column scale is applied by k_cam_reduce64
+// like for F'F).  Camera-major pass shaped like k_mf_camrows: one wave per segment of one camera, camera record
+// in scalar registers, the 45 upper-triangle sums per lane, one LDS cross-lane reduction.  Row sg of slab.
+__global__ __launch_bounds__(256) void k_mf_schurdiag(int n_seg, const int4* __restrict__ seg /*{cam, first, count, -}*/,
+                                                      const int32_t* __restrict__ cmo_pt, const double* __restrict__ ct,
+                                                      const double* __restrict__ cm, const double* __restrict__ ptrec,
+                                                      double* __restrict__ slab /*[n_seg][64]*/) {
+  __shared__ double s_red[4][64 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sg = blockIdx.x * 4 + wv;
+  if (sg >= n_seg) return;
+  const int4 Sg = seg[sg];
+  const int cam = __builtin_amdgcn_readfirstlane(Sg.x);
+  const int first = __builtin_amdgcn_readfirstlane(Sg.y), n = __builtin_amdgcn_readfirstlane(Sg.z);
+  double cd[kCamLds], one[9];
+  mf_stage_cam_init(cd, cam, ct, cm);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) one[k] = 1.0;
+  double acc[45];
+#pragma unroll
+  for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+  const int32_t* ptp = cmo_pt + first;
+  int32_t pt_c = ptp[min(lane, n - 1)];
+  for (int i = lane; i < n; i += 64) {
+    const int32_t pt_n = ptp[min(i + 64, n - 1)];
+    const double* rp = ptrec + (size_t)kPtRec * (size_t)pt_c;
+    double G[27], T[27];
+    dense_obs_G(cd, one, rp[0], rp[1], rp[2], G);
+    dense_WG(rp + 6, G, T);
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int b = a; b < 9; ++b) {
+        acc[o] = fma(G[a], T[b], fma(G[9 + a], T[9 + b], fma(G[18 + a], T[18 + b], acc[o])));
+        ++o;
+      }
+    pt_c = pt_n;
+  }
+  double* sr = s_red[wv];
+  const int sub = lane / 9, k9 = lane % 9;
+  double* row = slab + (size_t)kK2W * sg;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sr[lane * 9 + k] = acc[9 * r + k];
+    __builtin_amdgcn_wave_barrier();
+    double a = 0.0;
+    if (lane < 63)
+      for (int l = sub; l < 64; l += 7) a += sr[l * 9 + k9];
+    double tot = a;
+#pragma unroll
+    for (int s2 = 1; s2 < 7; ++s2) tot += __shfl(a, k9 + 9 * s2, 64);
+    if (lane < 9) row[9 * r + lane] = tot;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < 19) row[45 + lane] = 0.0;
+}
+
 // S += block diagonal B = F_s'F_s + D_c^2 (acc: upper triangle of F_s'F_s per camera), unit diagonal on the padding
 __global__ void k_dense_diag(int n_cam, const double* __restrict__ acc /*[n][64]*/, const double* __restrict__ Dc2,
                              double* __restrict__ S, int N) {

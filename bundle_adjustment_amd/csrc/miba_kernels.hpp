@@ -823,7 +823,9 @@ __global__ __launch_bounds__(256) void k_cam_reduce64(int n_cam, const int32_t* 
 // Camera blocks: B = F'F + D^2 -> M^-1 (9x9 Cholesky inverse), rhs, unscaled gradient norms.
 // acc[c][64] = {F'F upper 45, rhs 9, F'r 9}.  One thread per camera.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const uint8_t* __restrict__ active,
+// acc2 (SCHUR_JACOBI, else null): upper triangle of sum G'WG per camera, subtracted from B before the inversion,
+// so that M is the block diagonal of S itself (the LM diagonal is still taken from F'F).
+__global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const double* __restrict__ acc2, const uint8_t* __restrict__ active,
                              const double* __restrict__ sc, double inv_radius, double dmin, double dmax,
                              double* __restrict__ Minv /*[n][81]*/, double* __restrict__ Dc2 /*[n][9]*/,
                              double* __restrict__ rhs /*[n][9]*/, double* __restrict__ partial /*[nblk][2]*/,
@@ -846,6 +848,12 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const ui
         gmax = fmax(gmax, fabs(gu));
         g2 += gu * gu;
       }
+    }
+    if (acc2) {
+      const double* a2 = acc2 + (size_t)kK2W * c;
+      o = 0;
+      for (int i = 0; i < 9; ++i)
+        for (int j = i; j < 9; ++j) { L[j * 9 + i] -= a2[o]; if (j != i) L[i * 9 + j] -= a2[o]; ++o; }
     }
     // in-place lower Cholesky
     bool ok = true;

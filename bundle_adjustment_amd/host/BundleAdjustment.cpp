@@ -160,6 +160,7 @@ void BundleAdjustment::solve() {
     o.max_num_iterations = options.max_num_iterations;
     o.linear_solver_type = (int) options.linear_solver_type;
     o.jacobi_scaling = options.jacobi_scaling ? 1 : 0;
+    o.preconditioner_type = options.preconditioner_type == ceres::SCHUR_JACOBI ? MIBA_PRECOND_SCHUR_JACOBI : MIBA_PRECOND_JACOBI;
     o.max_linear_solver_iterations = options.max_linear_solver_iterations;
     o.min_linear_solver_iterations = options.min_linear_solver_iterations;
     o.max_num_consecutive_invalid_steps = options.max_num_consecutive_invalid_steps;
@@ -205,7 +206,9 @@ void BundleAdjustment::solve() {
     summary.residual_evaluation_time_in_seconds = ms.residual_time_in_seconds;
     summary.linear_solver_type_given = options.linear_solver_type;
     summary.linear_solver_used = options.linear_solver_type == ceres::ITERATIVE_SCHUR
-                                 ? "ITERATIVE_SCHUR (HIP implicit-Schur PCG, JACOBI preconditioner)"
+                                 ? (options.preconditioner_type == ceres::SCHUR_JACOBI
+                                        ? "ITERATIVE_SCHUR (HIP implicit-Schur PCG, SCHUR_JACOBI preconditioner)"
+                                        : "ITERATIVE_SCHUR (HIP implicit-Schur PCG, JACOBI preconditioner)")
                                  : ms.exact_linear_solver
                                        ? "DENSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device)"
                                        : "ITERATIVE_SCHUR (HIP implicit-Schur PCG run to q-tolerance 1e-12 in place of the exact solver: "

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MIBA_LIB", os.path.join(_HERE, "libmiba.so"))   # MIB
 
 (DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR,
  ITERATIVE_SCHUR, CGNR) = range(7)
+PRECOND_JACOBI, PRECOND_SCHUR_JACOBI = 0, 1
 CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE = range(5)
 K_EVAL_JAC, K_EVAL_COST, K_SCHUR_INIT, K_SCHUR_MATVEC, K_BACKSUB = range(5)
 K_COUNT = 8
@@ -50,7 +51,7 @@ class Options(C.Structure):
                 ("max_num_consecutive_invalid_steps", C.c_int32),
                 ("update_state_every_iteration", C.c_int32),
                 ("minimizer_progress_to_stdout", C.c_int32), ("pcg_check_every", C.c_int32),
-                ("reserved0", C.c_int32),
+                ("preconditioner_type", C.c_int32),
                 ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),

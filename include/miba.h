@@ -94,10 +94,14 @@ typedef struct {
   const double* obs_xy;
 } miba_problem;
 
+/* preconditioner of the implicit-Schur PCG: block diagonal of the camera part B = F'F + D^2 (Ceres' JACOBI,
+ * the default the reference runs with) or of the Schur complement itself (Ceres' SCHUR_JACOBI) */
+enum { MIBA_PRECOND_JACOBI = 0, MIBA_PRECOND_SCHUR_JACOBI = 1 };
+
 typedef struct {
   int32_t max_num_iterations;               /* app/main.cpp:27 -> 80; Ceres default 50 */
-  int32_t linear_solver_type;               /* MIBA_* above; all but ITERATIVE_SCHUR are run
-                                               as tight-tolerance PCG (eta_exact) and reported so */
+  int32_t linear_solver_type;               /* MIBA_* above; all but ITERATIVE_SCHUR are solved exactly on the device
+                                               (<= 2048 cameras) or as tight-tolerance PCG (eta_exact), and reported so */
   int32_t jacobi_scaling;                   /* 1 */
   int32_t max_linear_solver_iterations;     /* 500 */
   int32_t min_linear_solver_iterations;     /* 0 */
@@ -105,7 +109,8 @@ typedef struct {
   int32_t update_state_every_iteration;     /* src/BundleAdjustment.cpp:104 */
   int32_t minimizer_progress_to_stdout;     /* app/main.cpp:26 */
   int32_t pcg_check_every;                  /* host polls the device PCG status every N its (>=1) */
-  int32_t reserved0;
+  int32_t preconditioner_type;              /* MIBA_PRECOND_*: ceres::Solver::Options::preconditioner_type for
+                                               ITERATIVE_SCHUR; the reference leaves Ceres' default, JACOBI */
   double initial_trust_region_radius;       /* 1e4 */
   double max_trust_region_radius;           /* 1e16 */
   double min_trust_region_radius;           /* 1e-32 */

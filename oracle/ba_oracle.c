@@ -438,7 +438,7 @@ static void schur_free(schur_t* S) {
 }
 
 /* ImplicitSchurComplement::Init: block inverses + rhs = F'(b - E C^-1 E'b). */
-static int schur_init(prob_t* P, schur_t* S) {
+static int schur_init(prob_t* P, schur_t* S, int schur_jacobi) {
   const int n_cam = P->n_cam, n_pt = P->n_pt;
   const size_t w81 = 81 * (size_t)n_cam;
   int fail = 0;
@@ -467,12 +467,43 @@ static int schur_init(prob_t* P, schur_t* S) {
   if (fail) return -1;
   memset(S->FtF, 0, sizeof(double) * w81);
   reduce_tbuf(P, 81, S->FtF);
+  /* SCHUR_JACOBI (ceres::PreconditionerType, SchurJacobiPreconditioner): the preconditioner is the block diagonal
+     of S itself, B_c - sum_{obs of c} (E'F)' C_p^-1 (E'F), instead of the block diagonal B_c of the camera part */
+  double* Sd = NULL;
+  if (schur_jacobi) {
+    Sd = (double*)calloc(w81 ? w81 : 1, sizeof(double));
+    if (!Sd) return -1;
+    memset(P->tbuf, 0, sizeof(double) * (size_t)P->n_thr * w81);
+#pragma omp parallel for schedule(static) num_threads(P->n_thr)
+    for (int p = 0; p < n_pt; ++p) {
+      double* acc = P->tbuf + (size_t)thr_id() * w81;
+      const double* Ci = S->Cinv + 9 * (size_t)p;
+      for (int64_t s = P->pt_off[p]; s < P->pt_off[p + 1]; ++s) {
+        const double* E = P->E + 6 * s;
+        const double* F = P->F + 18 * s;
+        double G[27], T[27];
+        for (int a = 0; a < 3; ++a)
+          for (int k = 0; k < 9; ++k) G[9 * a + k] = E[a] * F[k] + E[3 + a] * F[9 + k];
+        for (int a = 0; a < 3; ++a)
+          for (int k = 0; k < 9; ++k) T[9 * a + k] = Ci[a * 3] * G[k] + Ci[a * 3 + 1] * G[9 + k] + Ci[a * 3 + 2] * G[18 + k];
+        double* D = acc + 81 * (size_t)P->cam[s];
+        for (int i = 0; i < 9; ++i)
+          for (int j = 0; j < 9; ++j) D[i * 9 + j] += G[i] * T[j] + G[9 + i] * T[9 + j] + G[18 + i] * T[18 + j];
+      }
+    }
+    reduce_tbuf(P, 81, Sd);
+  }
 #pragma omp parallel for schedule(static) num_threads(P->n_thr) reduction(| : fail)
   for (int c = 0; c < n_cam; ++c) {
     double* B = S->FtF + 81 * (size_t)c;
     for (int i = 0; i < 9; ++i) B[i * 9 + i] += S->Dc2[9 * (size_t)c + i];
-    if (spd_inverse(9, B, S->Minv + 81 * (size_t)c)) fail |= 1;
+    if (Sd) {
+      double M[81];
+      for (int i = 0; i < 81; ++i) M[i] = B[i] - Sd[81 * (size_t)c + i];
+      if (spd_inverse(9, M, S->Minv + 81 * (size_t)c)) fail |= 1;
+    } else if (spd_inverse(9, B, S->Minv + 81 * (size_t)c)) fail |= 1;
   }
+  free(Sd);
   if (fail) return -1;
   /* pass 2: rhs = F'(b - E C^-1 g_p) */
   const size_t w9 = 9 * (size_t)n_cam;
@@ -708,7 +739,7 @@ static int lm_linear_solve(prob_t* P, schur_t* S, const bao_options* o, const do
   for (size_t i = 0; i < nc9; ++i) S->Dc2[i] = diag_c[i] / radius; /* D = sqrt(diag/radius) => D^2 */
   for (size_t i = 0; i < np3; ++i) S->Dp2[i] = diag_p[i] / radius;
   *n_cg = 0;
-  if (schur_init(P, S)) return 2;
+  if (schur_init(P, S, o->preconditioner == BAO_SCHUR_JACOBI)) return 2;
   int st;
   if (o->linear_solver == BAO_DENSE_NORMAL) {
     st = normal_dense_solve(P, S, yc, yp);

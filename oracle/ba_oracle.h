@@ -39,6 +39,9 @@ enum {
   BAO_DENSE_NORMAL = 2     /* full dense normal equations + Cholesky (tiny problems)  */
 };
 
+/* ceres::PreconditionerType for ITERATIVE_SCHUR (the reference leaves Ceres' default, JACOBI) */
+enum { BAO_JACOBI = 0, BAO_SCHUR_JACOBI = 1 };
+
 typedef struct {
   int max_num_iterations;              /* app/main.cpp:27 sets 80; Ceres default 50 */
   int linear_solver;                   /* BAO_* above */
@@ -47,7 +50,7 @@ typedef struct {
   int min_linear_solver_iterations;    /* 0 */
   int max_num_consecutive_invalid_steps; /* 5 */
   int num_threads;                     /* OpenMP threads; app/main.cpp:28 sets 4 */
-  int reserved;
+  int preconditioner;                  /* BAO_JACOBI (Ceres default) or BAO_SCHUR_JACOBI, for ITERATIVE_SCHUR */
   double initial_trust_region_radius;  /* 1e4 */
   double max_trust_region_radius;      /* 1e16 */
   double min_trust_region_radius;      /* 1e-32 */

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libba_oracle.so")
 
 ITERATIVE_SCHUR, DENSE_SCHUR, DENSE_NORMAL = 0, 1, 2
+JACOBI, SCHUR_JACOBI = 0, 1
 
 
 class Options(C.Structure):
@@ -24,7 +25,7 @@ class Options(C.Structure):
         ("min_linear_solver_iterations", C.c_int),
         ("max_num_consecutive_invalid_steps", C.c_int),
         ("num_threads", C.c_int),
-        ("reserved", C.c_int),
+        ("preconditioner", C.c_int),
         ("initial_trust_region_radius", C.c_double),
         ("max_trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double),

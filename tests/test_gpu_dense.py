@@ -168,3 +168,39 @@ def test_dense_env_switch_falls_back_to_pcg(medium):
     finally:
         os.environ.pop("MIBA_DENSE", None)
     assert out["n_cg"] > 1
+
+
+def test_schur_jacobi_preconditioner_matches_oracle(oracle, medium):
+    """ceres::SCHUR_JACOBI (block diagonal of S itself as the PCG preconditioner; k_mf_schurdiag): same PCG
+    recurrence as the oracle run with the same preconditioner => same iteration counts and steps; and the
+    preconditioner blocks are the inverse diagonal blocks of the explicit S."""
+    pr, cams0, pts0 = medium
+    sc, sp = oracle.jacobi_scale(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    s = make_solver(pr, cams0, pts0)
+    for pc_m, pc_o in ((miba.PRECOND_JACOBI, oracle.JACOBI), (miba.PRECOND_SCHUR_JACOBI, oracle.SCHUR_JACOBI)):
+        for eta in (0.1, 1e-6):
+            out = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, eta=eta, preconditioner_type=pc_m))
+            ref = oracle.linear_step(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], 1e4, sc, sp,
+                                     oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, eta=eta, preconditioner=pc_o))
+            assert out["n_cg"] == ref["n_cg"], (pc_m, eta, out["n_cg"], ref["n_cg"])
+            assert rel(out["y_cam"], ref["y_cam"]) <= 1e-7
+            assert abs(out["model_cost_change"] - ref["model_cost_change"]) <= 1e-9 * abs(ref["model_cost_change"])
+    s.close()
+
+
+def test_schur_jacobi_lm_run_matches_oracle(oracle, medium):
+    pr, cams0, pts0 = medium
+    kw = dict(max_num_iterations=8, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+    s = make_solver(pr, cams0, pts0)
+    its, summ = s.solve(miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, preconditioner_type=miba.PRECOND_SCHUR_JACOBI, **kw))
+    s.close()
+    _, _, oits, osumm = oracle.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"],
+                                     oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, preconditioner=oracle.SCHUR_JACOBI, **kw))
+    n_cmp = 1
+    while n_cmp < len(oits) and abs(oits[n_cmp]["cost_change"]) > 1e-9 * oits[n_cmp]["cost"]:
+        n_cmp += 1
+    assert n_cmp >= 4
+    for a, b in zip(its[:n_cmp], oits[:n_cmp]):
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(b["cost"]), (a, b)
+        assert a["linear_solver_iterations"] == b["linear_solver_iterations"]
+    assert abs(summ["final_cost"] - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"]
