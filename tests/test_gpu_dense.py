@@ -66,10 +66,13 @@ def test_cholesky_reports_indefinite_matrix():
 def assembly(request):
     """Both assembly kernels: the host-planned, atomic-free k_dense_blocks (default) and k_dense_pairs /
     k_dense_pairs_giant (global atomics, used when the pair plan would be too large)."""
-    if request.param == "atomics":
-        os.environ["MIBA_DENSE_PLAN"] = "0"
+    old = os.environ.get("MIBA_DENSE_PLAN")
+    os.environ["MIBA_DENSE_PLAN"] = "0" if request.param == "atomics" else "1"
     yield request.param
-    os.environ.pop("MIBA_DENSE_PLAN", None)
+    if old is None:
+        os.environ.pop("MIBA_DENSE_PLAN", None)
+    else:
+        os.environ["MIBA_DENSE_PLAN"] = old
 
 
 def test_reduced_system_matches_implicit_operator(medium, assembly):

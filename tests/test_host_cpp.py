@@ -102,7 +102,8 @@ def test_app_main_end_to_end(tmp_path, oracle):
     assert head[0] == "ply" and head[2] == "element vertex %d" % (600 + 20)
     assert head[10].endswith(" 0 255 0") and "Solver Summary" in out.stdout
     # a factorisation-based solver type on a small problem is served by the device Cholesky, and the report says so
-    assert "blocked Cholesky on the device" in out.stdout, out.stdout[-2000:]
+    if os.environ.get("MIBA_MF", "1") != "0" and os.environ.get("MIBA_DENSE", "1") != "0":
+        assert "blocked Cholesky on the device" in out.stdout, out.stdout[-2000:]
 
 
 @pytest.mark.gpu

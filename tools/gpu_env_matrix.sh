@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU test suite under every environment knob of libmiba (run on the GPU box: bash tools/gpu_env_matrix.sh)
+set -o pipefail
+run() { echo "== $*"; env "$@" timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread $EXTRA 2>&1 | tail -2 || exit 1; }
+EXTRA=""
+run MIBA_TILE_CHUNKS=1 || exit 1
+run MIBA_TILE_CHUNKS=16 || exit 1
+run MIBA_POINT_ORDER=0 || exit 1
+run MIBA_FORCE_RCCL=1 || exit 1
+run MIBA_DENSE_PLAN=0 || exit 1
+# the exact solve and SCHUR_JACOBI need the two-pass matrix-free kernels: their tests are skipped for these three
+EXTRA="--deselect tests/test_gpu_dense.py"
+run MIBA_K2_ONEPASS=1 || exit 1
+run MIBA_MF=0 || exit 1
+run MIBA_DENSE=0 || exit 1
