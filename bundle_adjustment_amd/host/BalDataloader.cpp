@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <sys/stat.h>
 #include <thread>
 #include <tuple>
 #include <vector>
@@ -109,7 +110,71 @@ bool parse_token(const char *b, const char *e, float &out) {
     return true;
 }
 
+// Binary cache of the parsed arrays, opt-in with BA_LOADER_CACHE=1: <path>.mibacache holds
+// the float-rounded values exactly as the text parse produced them, keyed by the text file's size and mtime.
+struct CacheHeader {
+    char magic[8];
+    long long src_size, src_mtime_ns;
+    int n_cam, n_pt, n_obs, pad;
+};
+const char kCacheMagic[8] = {'M', 'I', 'B', 'A', 'B', 'A', 'L', '1'};
+
+bool cache_key(const std::string &path, CacheHeader &h) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return false;
+    memcpy(h.magic, kCacheMagic, 8);
+    h.src_size = (long long) st.st_size;
+    h.src_mtime_ns = (long long) st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
+    return true;
+}
+
 }  // namespace
+
+// false: no usable cache (missing, stale, short): the caller parses the text
+static bool load_cache(BalDataloader &d, const std::string &path) {
+    CacheHeader want{}, got{};
+    if (!cache_key(path, want)) return false;
+    FILE *fp = fopen((path + ".mibacache").c_str(), "rb");
+    if (!fp) return false;
+    bool ok = fread(&got, sizeof(got), 1, fp) == 1 && memcmp(got.magic, kCacheMagic, 8) == 0 && got.src_size == want.src_size &&
+              got.src_mtime_ns == want.src_mtime_ns && got.n_cam >= 0 && got.n_pt >= 0 && got.n_obs >= 0;
+    if (ok) {
+        std::vector<int> oc((size_t) got.n_obs), op((size_t) got.n_obs);
+        d.observations.resize((size_t) got.n_obs);
+        d.cameras.resize((size_t) got.n_cam);
+        d.points.resize((size_t) got.n_pt);
+        static_assert(sizeof(std::pair<float, float>) == 8 && sizeof(Camera) == 36 && sizeof(std::tuple<float, float, float>) == 12,
+                      "cache layout");
+        auto rd = [&](void *dst, size_t bytes) { return bytes == 0 || fread(dst, 1, bytes, fp) == bytes; };
+        ok = rd(oc.data(), oc.size() * sizeof(int)) && rd(op.data(), op.size() * sizeof(int)) &&
+             rd(d.observations.data(), d.observations.size() * 8) && rd(d.cameras.data(), d.cameras.size() * sizeof(Camera)) &&
+             rd(d.points.data(), d.points.size() * 12);
+        if (ok) {
+            d.obs_cam.resize(oc.size());
+            d.obs_point.resize(op.size());
+            for (size_t i = 0; i < oc.size(); ++i) { d.obs_cam[i] = (size_t) (long long) oc[i]; d.obs_point[i] = (size_t) (long long) op[i]; }
+            d.num_camera = got.n_cam; d.num_points = got.n_pt; d.num_observations = got.n_obs;
+        }
+    }
+    fclose(fp);
+    return ok;
+}
+
+static void store_cache(const BalDataloader &d, const std::string &path) {
+    CacheHeader h{};
+    if (!cache_key(path, h)) return;
+    h.n_cam = d.num_camera; h.n_pt = d.num_points; h.n_obs = d.num_observations;
+    std::vector<int> oc(d.obs_cam.size()), op(d.obs_point.size());
+    for (size_t i = 0; i < oc.size(); ++i) { oc[i] = (int) (long long) d.obs_cam[i]; op[i] = (int) (long long) d.obs_point[i]; }
+    const std::string tmp = path + ".mibacache.tmp";
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    if (!fp) return;   // read-only dataset directory: no cache, no error
+    auto wr = [&](const void *src, size_t bytes) { return bytes == 0 || fwrite(src, 1, bytes, fp) == bytes; };
+    const bool ok = wr(&h, sizeof(h)) && wr(oc.data(), oc.size() * sizeof(int)) && wr(op.data(), op.size() * sizeof(int)) &&
+                    wr(d.observations.data(), d.observations.size() * 8) && wr(d.cameras.data(), d.cameras.size() * sizeof(Camera)) &&
+                    wr(d.points.data(), d.points.size() * 12);
+    if (fclose(fp) != 0 || !ok || rename(tmp.c_str(), (path + ".mibacache").c_str()) != 0) remove(tmp.c_str());
+}
 
 BalDataloader::BalDataloader(std::string path) {
     // <num_cameras> <num_points> <num_observations>
@@ -121,6 +186,9 @@ BalDataloader::BalDataloader(std::string path) {
         if (getenv("BA_LOADER_DEBUG"))
             fprintf(stderr, "[BalDataloader] %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     };
+    const char *ce = getenv("BA_LOADER_CACHE");
+    const bool use_cache = ce && atoi(ce) != 0;
+    if (use_cache && load_cache(*this, path)) { lap("binary cache read"); return; }
     FILE *fp = fopen(path.c_str(), "rb");
     if (!fp) { throw std::invalid_argument("File could not be opened"); }
     std::vector<char> buf;
@@ -236,6 +304,7 @@ BalDataloader::BalDataloader(std::string path) {
     lap("parsed");
     for (unsigned t = 0; t < n_thr; ++t)
         if (bad[t]) { throw std::invalid_argument("Not a BAL file (unparsable number)"); }
+    if (use_cache) { store_cache(*this, path); lap("binary cache written"); }
 }
 
 BalDataloader::~BalDataloader() {}

@@ -158,3 +158,31 @@ def test_bal_loader_threaded_parse_equals_serial(tmp_path):
     open(p3, "w").write(txt[: len(txt) // 2])
     out = subprocess.run([CHECK, "--loader", p3], capture_output=True, text=True, timeout=120)
     assert out.returncode == 3 and "truncated" in out.stdout
+
+
+def test_bal_loader_binary_cache(tmp_path):
+    """BA_LOADER_CACHE=1: the second load comes from <file>.mibacache and is identical to the text
+    parse (including a -1 point index); a changed text file invalidates the cache; without the knob nothing is written."""
+    pr = synth.make_problem(12, 500, 2200, seed=9)
+    path = str(tmp_path / "problem-12-500-pre.txt")
+    synth.write_bal(path, pr)
+    lines = open(path).read().split("\n")
+    t = lines[5].split(); t[1] = "-1"; lines[5] = " ".join(t)    # an observation the solver will skip
+    open(path, "w").write("\n".join(lines))
+    plain = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=60)
+    assert plain.returncode == 0 and not os.path.exists(path + ".mibacache")
+    env = dict(os.environ, BA_LOADER_CACHE="1", BA_LOADER_DEBUG="1")
+    first = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=60, env=env)
+    assert first.returncode == 0 and "binary cache written" in first.stderr and os.path.exists(path + ".mibacache")
+    second = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=60, env=env)
+    assert second.returncode == 0 and "binary cache read" in second.stderr
+    assert plain.stdout == first.stdout == second.stdout
+    # stale cache: the text changes (size differs), the loader parses again and rewrites
+    lines[7] = lines[7] + "0"
+    open(path, "w").write("\n".join(lines))
+    third = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=60, env=env)
+    assert third.returncode == 0 and "binary cache read" not in third.stderr and "binary cache written" in third.stderr
+    # a damaged cache is ignored
+    open(path + ".mibacache", "r+b").truncate(100)
+    fourth = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=60, env=env)
+    assert fourth.returncode == 0 and "binary cache read" not in fourth.stderr and fourth.stdout == third.stdout

@@ -14,4 +14,8 @@ exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'app', 'ba_
 for thr in ("1", "4", "16"):
     r = subprocess.run([exe, "--loader-time", path], capture_output=True, text=True, env=dict(os.environ, BA_LOADER_THREADS=thr))
     print("threads", thr, r.stdout.strip(), flush=True)
+for label in ("cache write", "cache read"):
+    r = subprocess.run([exe, "--loader-time", path], capture_output=True, text=True, env=dict(os.environ, BA_LOADER_CACHE="1"))
+    print(label, r.stdout.strip(), flush=True)
 os.remove(path)
+os.remove(path + ".mibacache")
