@@ -8,6 +8,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -43,6 +50,36 @@ struct EvPair {
   int kid;
 };
 
+// TEST transport (MIBA_TEST_SHM_COMM=<name>): the all-reduces of a multi-rank world staged through a POSIX
+// shared-memory segment between processes, so that the whole multi-rank control flow (sharding, what is
+// reduced when, identical decisions on every rank) can be run and checked with several processes on ONE GPU,
+// where RCCL refuses to put two ranks.  Blocking and slow by design; never used unless the variable is set.
+constexpr size_t kShmChunk = (size_t)1 << 19;   // doubles per rank slot (4 MiB)
+struct ShmHeader {
+  std::atomic<int> count;
+  std::atomic<int> gen;
+  char pad[56];
+};
+struct ShmComm {
+  std::string name;
+  void* base = nullptr;
+  size_t bytes = 0;
+  int world = 0, rank = 0;
+  std::vector<double> host;
+  ShmHeader* hdr() { return (ShmHeader*)base; }
+  double* slot(int r) { return (double*)((char*)base + sizeof(ShmHeader)) + (size_t)r * kShmChunk; }
+  void barrier() {
+    ShmHeader* H = hdr();
+    const int g = H->gen.load(std::memory_order_acquire);
+    if (H->count.fetch_add(1, std::memory_order_acq_rel) + 1 == world) {
+      H->count.store(0, std::memory_order_relaxed);
+      H->gen.store(g + 1, std::memory_order_release);
+    } else {
+      while (H->gen.load(std::memory_order_acquire) == g) sched_yield();
+    }
+  }
+};
+
 }  // namespace
 
 struct miba_handle_s {
@@ -50,6 +87,7 @@ struct miba_handle_s {
   int device = 0;
   hipStream_t st = nullptr;
   ncclComm_t comm = nullptr;
+  ShmComm* shm = nullptr;    // test transport instead of RCCL (see ShmComm)
   std::string err;
   bool has_problem = false;
 
@@ -207,11 +245,37 @@ int sync_stream(miba_handle h) {
 // blocks for n items; never 0 (an empty shard still launches one block whose bounds checks do nothing)
 inline int nblk(size_t n, int bs) { return n ? (int)((n + bs - 1) / bs) : 1; }
 
+int allreduce_shm(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
+  ShmComm& C = *h->shm;
+  C.host.resize(kShmChunk);
+  for (size_t o = 0; o < n; o += kShmChunk) {
+    const size_t m = std::min(kShmChunk, n - o);
+    HIPCHK(h, hipMemcpyAsync(C.host.data(), buf + o, m * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    memcpy(C.slot(C.rank), C.host.data(), m * sizeof(double));
+    C.barrier();
+    // every rank combines the slots in rank order: the same bits everywhere
+    for (size_t i = 0; i < m; ++i) {
+      double v = C.slot(0)[i];
+      for (int r = 1; r < C.world; ++r) v = (op == ncclMax) ? std::max(v, C.slot(r)[i]) : v + C.slot(r)[i];
+      C.host[i] = v;
+    }
+    C.barrier();
+    HIPCHK(h, hipMemcpyAsync(buf + o, C.host.data(), m * sizeof(double), hipMemcpyHostToDevice, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+  }
+  return MIBA_OK;
+}
+
 int allreduce(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
+  if (h->shm) return allreduce_shm(h, buf, n, op);
   if (!h->comm) return MIBA_OK;
   NCCLCHK(h, ncclAllReduce(buf, buf, n, ncclDouble, op, h->comm, h->st));
   return MIBA_OK;
 }
+
+// more than one rank contributes to the sums (RCCL or the test transport)
+inline bool multi_rank(miba_handle h) { return h->comm != nullptr || h->shm != nullptr; }
 
 // ---- building blocks -----------------------------------------------------------------------
 int launch_cam_tables(miba_handle h, const double* cam, bool candidate = false) {
@@ -384,7 +448,7 @@ int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* pa
     // x.y is linear in y, so with several ranks the per-block partials of x.y_local are all-reduced together with
     // y_local (the caller places them right behind y): every rank then sums the same red_nb numbers
     const bool tail = part_xy && part_xy == y + 9 * (size_t)h->n_cam;
-    if (h->comm && part_xy && !tail) return fail(h, MIBA_ERR_INVALID, "x.y partials must follow y for the all-reduce");
+    if (multi_rank(h) && part_xy && !tail) return fail(h, MIBA_ERR_INVALID, "x.y partials must follow y for the all-reduce");
     return allreduce(h, y, 9 * (size_t)h->n_cam + (tail ? (size_t)h->red_nb : 0), ncclSum);
   }
   if (h->n_tiles) {
@@ -847,7 +911,25 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
   // un-reduced partial sums can be inspected on a single GPU; solves are meaningless in this mode
   const char* nocomm = getenv("MIBA_TEST_NO_COMM");
   const bool no_comm = nocomm && nocomm[0] == '1';
-  if (!no_comm && (cfg->world_size > 1 || (force && force[0] == '1'))) {
+  const char* shm_name = getenv("MIBA_TEST_SHM_COMM");
+  if (!no_comm && cfg->world_size > 1 && shm_name && shm_name[0]) {
+    ShmComm* C = new ShmComm();
+    C->name = std::string("/") + shm_name;
+    C->world = cfg->world_size;
+    C->rank = cfg->rank;
+    C->bytes = sizeof(ShmHeader) + (size_t)cfg->world_size * kShmChunk * sizeof(double);
+    const int fd = shm_open(C->name.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)C->bytes) != 0) {
+      if (fd >= 0) close(fd);
+      delete C; delete h;
+      return fail(nullptr, MIBA_ERR_INVALID, "MIBA_TEST_SHM_COMM: cannot create shared memory %s", shm_name);
+    }
+    C->base = mmap(nullptr, C->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (C->base == MAP_FAILED) { delete C; delete h; return fail(nullptr, MIBA_ERR_NOMEM, "MIBA_TEST_SHM_COMM: mmap failed"); }
+    h->shm = C;
+    C->barrier();   // every rank has mapped the (zero-filled) segment
+  } else if (!no_comm && (cfg->world_size > 1 || (force && force[0] == '1'))) {
     ncclUniqueId id;
     if (cfg->comm_unique_id) memcpy(&id, cfg->comm_unique_id, sizeof(id));
     else if (cfg->world_size == 1) {
@@ -872,6 +954,12 @@ int miba_destroy(miba_handle h) {
   drain_events(h);
   for (auto& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (h->comm) (void)ncclCommDestroy(h->comm);
+  if (h->shm) {
+    h->shm->barrier();   // nobody is inside a reduction any more
+    munmap(h->shm->base, h->shm->bytes);
+    if (h->shm->rank == 0) shm_unlink(h->shm->name.c_str());
+    delete h->shm;
+  }
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   if (h->st) (void)hipStreamDestroy(h->st);
@@ -1173,19 +1261,19 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
   if (!X) return MIBA_OK;
   const size_t n_act = h->plan.pt_orig.size();
   std::vector<double> pts(3 * (n_act ? n_act : 1), 0.0);
-  if (h->comm && h->cfg.world_size > 1) {
+  if (multi_rank(h) && h->cfg.world_size > 1) {
     // every rank contributes its own points to a zero-filled buffer; sum = gather
     double* d_all = nullptr;
     HIPCHK(h, hipMalloc((void**)&d_all, 3 * (n_act ? n_act : 1) * sizeof(double)));
     hipError_t e = hipMemsetAsync(d_all, 0, 3 * n_act * sizeof(double), h->st);
     if (e == hipSuccess && h->n_pt)
       e = hipMemcpyAsync(d_all + 3 * (size_t)h->pt_base, h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToDevice, h->st);
-    ncclResult_t r = ncclSuccess;
-    if (e == hipSuccess) r = ncclAllReduce(d_all, d_all, 3 * n_act, ncclDouble, ncclSum, h->comm, h->st);
-    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(pts.data(), d_all, 3 * n_act * sizeof(double), hipMemcpyDeviceToHost, h->st);
+    int rcg = MIBA_OK;
+    if (e == hipSuccess) rcg = allreduce(h, d_all, 3 * n_act, ncclSum);
+    if (e == hipSuccess && rcg == MIBA_OK) e = hipMemcpyAsync(pts.data(), d_all, 3 * n_act * sizeof(double), hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     (void)hipFree(d_all);
-    if (r != ncclSuccess) return fail(h, MIBA_ERR_RCCL, "all-gather of points failed: %s", ncclGetErrorString(r));
+    if (rcg != MIBA_OK) return rcg;
     if (e != hipSuccess) return fail(h, MIBA_ERR_HIP, "point download failed: %s", hipGetErrorString(e));
     for (size_t s = 0; s < n_act; ++s) {
       const size_t o = (size_t)h->plan.pt_orig[s];
