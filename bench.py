@@ -67,17 +67,25 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus)
+    # Rehearsal on ONE GPU (RCCL refuses two ranks on a device): with MIBA_TEST_SHM_COMM set, libmiba's all-reduces go
+    # through its shared-memory test transport, torch.distributed uses gloo and every rank uses device 0.  The numbers
+    # of such a run mean nothing; it exists so that this script's multi-rank control flow can be run before the driver does.
+    rehearsal = world > 1 and bool(os.environ.get("MIBA_TEST_SHM_COMM"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    dist_dev = "cpu" if rehearsal else "cuda"
     uid = None
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")
-        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            t.copy_(torch.frombuffer(bytearray(miba.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(t, 0)
-        uid = bytes(t.cpu().numpy().tobytes())
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl")
+        if not rehearsal:
+            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(miba.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(t, 0)
+            uid = bytes(t.cpu().numpy().tobytes())
 
     n_cam, n_pt, n_obs, seed = synth.CONFIGS[args.config]
     t0 = time.time()
@@ -142,7 +150,7 @@ def main():
             solver.set_state(cams0, pts0)
     total = args.warmup + args.steps
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=dist_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kt = solver.kernel_times()
