@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "bundleadjust/BAConstraint.h"
+#include "bundleadjust/BalDataloader.h"
+#include "bundleadjust/BundleAdjustment.h"
 
 // "--loader <file>": dump what BalDataloader parsed and what initialize() produced
 static int dump_loader(const char *path) {
@@ -50,7 +52,24 @@ static int time_loader(const char *path) {
     return 0;
 }
 
+// "--ply <file> <out.ply>": BundleAdjustment constructed on the loaded data (no createProblem, no GPU), its state dumped
+// with WriteToPLYFile; the state itself goes to stdout as hex doubles (translations, then points) so that the caller
+// can format the expected text independently.  The sequence of the reference's tests/procrustes/procrustes_test.cpp:27-34.
+static int dump_ply(const char *path, const char *out) {
+    BalDataloader d(path);
+    ceres::Solver::Options options;
+    BundleAdjustment ba{&d, options};
+    ba.WriteToPLYFile(out);
+    printf("%d %d\n", d.getNumFrames(), d.getNumPoints());
+    for (int i = 0; i < d.getNumFrames(); ++i) printf("%a %a %a\n", ba.getTranslation(i)[0], ba.getTranslation(i)[1], ba.getTranslation(i)[2]);
+    for (int i = 0; i < d.getNumPoints(); ++i) printf("%a %a %a\n", ba.getPoint(i)[0], ba.getPoint(i)[1], ba.getPoint(i)[2]);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 4 && std::string(argv[1]) == "--ply") {
+        try { return dump_ply(argv[2], argv[3]); } catch (const std::exception &e) { printf("exception %s\n", e.what()); return 3; }
+    }
     if (argc == 3 && std::string(argv[1]) == "--loader-time") {
         try { return time_loader(argv[2]); } catch (const std::invalid_argument &e) { printf("invalid_argument %s\n", e.what()); return 3; }
     }

@@ -135,6 +135,7 @@ struct miba_handle_s {
   std::vector<void*> allocs;
 
   // host pinned
+  double* h_stage = nullptr; size_t h_stage_n = 0;   // staging for miba_get_state (points), grown on demand
   double* h_scal = nullptr;   // 2*S_COUNT
   Ctl* h_ctl = nullptr;
 
@@ -960,6 +961,7 @@ int miba_destroy(miba_handle h) {
     if (h->shm->rank == 0) shm_unlink(h->shm->name.c_str());
     delete h->shm;
   }
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   if (h->st) (void)hipStreamDestroy(h->st);
@@ -1260,7 +1262,15 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
   }
   if (!X) return MIBA_OK;
   const size_t n_act = h->plan.pt_orig.size();
-  std::vector<double> pts(3 * (n_act ? n_act : 1), 0.0);
+  // pinned staging buffer, kept: per-iteration state pulls (update_state_every_iteration) copy at full PCIe rate
+  const size_t need = 3 * (n_act ? n_act : 1);
+  if (h->h_stage_n < need) {
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    h->h_stage = nullptr; h->h_stage_n = 0;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_stage, need * sizeof(double)));
+    h->h_stage_n = need;
+  }
+  double* pts = h->h_stage;
   if (multi_rank(h) && h->cfg.world_size > 1) {
     // every rank contributes its own points to a zero-filled buffer; sum = gather
     double* d_all = nullptr;
@@ -1270,24 +1280,30 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
       e = hipMemcpyAsync(d_all + 3 * (size_t)h->pt_base, h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToDevice, h->st);
     int rcg = MIBA_OK;
     if (e == hipSuccess) rcg = allreduce(h, d_all, 3 * n_act, ncclSum);
-    if (e == hipSuccess && rcg == MIBA_OK) e = hipMemcpyAsync(pts.data(), d_all, 3 * n_act * sizeof(double), hipMemcpyDeviceToHost, h->st);
+    if (e == hipSuccess && rcg == MIBA_OK) e = hipMemcpyAsync(pts, d_all, 3 * n_act * sizeof(double), hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     (void)hipFree(d_all);
     if (rcg != MIBA_OK) return rcg;
     if (e != hipSuccess) return fail(h, MIBA_ERR_HIP, "point download failed: %s", hipGetErrorString(e));
-    for (size_t s = 0; s < n_act; ++s) {
-      const size_t o = (size_t)h->plan.pt_orig[s];
-      X[3 * o] = pts[3 * s]; X[3 * o + 1] = pts[3 * s + 1]; X[3 * o + 2] = pts[3 * s + 2];
-    }
+    const int32_t* po = h->plan.pt_orig.data();
+    plan_parallel_for((int64_t)n_act, [&](int64_t a, int64_t b) {
+      for (int64_t s = a; s < b; ++s) {
+        const size_t o = (size_t)po[s];
+        X[3 * o] = pts[3 * s]; X[3 * o + 1] = pts[3 * s + 1]; X[3 * o + 2] = pts[3 * s + 2];
+      }
+    });
   } else {
     if (h->n_pt) {
-      HIPCHK(h, hipMemcpyAsync(pts.data(), h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToHost, h->st));
+      HIPCHK(h, hipMemcpyAsync(pts, h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToHost, h->st));
       HIPCHK(h, hipStreamSynchronize(h->st));
     }
-    for (int32_t q = 0; q < h->n_pt; ++q) {
-      const size_t o = (size_t)h->plan.pt_orig[h->pt_base + q];
-      X[3 * o] = pts[3 * (size_t)q]; X[3 * o + 1] = pts[3 * (size_t)q + 1]; X[3 * o + 2] = pts[3 * (size_t)q + 2];
-    }
+    const int32_t* po = h->plan.pt_orig.data() + h->pt_base;
+    plan_parallel_for((int64_t)h->n_pt, [&](int64_t a, int64_t b) {
+      for (int64_t q = a; q < b; ++q) {
+        const size_t o = (size_t)po[q];
+        X[3 * o] = pts[3 * q]; X[3 * o + 1] = pts[3 * q + 1]; X[3 * o + 2] = pts[3 * q + 2];
+      }
+    });
   }
   return MIBA_OK;
 }

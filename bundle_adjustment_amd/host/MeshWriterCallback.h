@@ -19,6 +19,10 @@ public:
 
     ~MeshWriterCallback() {}
 
+    // false: BA_ITERATION_PLY=0, the callback would do nothing (solve() then leaves it out, so that no state is
+    // copied back per iteration on its account)
+    bool isEnabled() const { return enabled; }
+
     ceres::CallbackReturnType operator()(const ceres::IterationSummary &summary) {
         if(enabled && summary.iteration % 1 == 0) {
             char name[256];

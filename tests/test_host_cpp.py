@@ -186,3 +186,28 @@ def test_bal_loader_binary_cache(tmp_path):
     open(path + ".mibacache", "r+b").truncate(100)
     fourth = subprocess.run([CHECK, "--loader", path], capture_output=True, text=True, timeout=60, env=env)
     assert fourth.returncode == 0 and "binary cache read" not in fourth.stderr and fourth.stdout == third.stdout
+
+
+def test_ply_writer_text_equals_printf(tmp_path):
+    """WriteToPLYFile (threaded, std::to_chars) writes exactly the text of the reference's
+    `"%.4f %.4f %.4f r g b"` lines (src/BundleAdjustment.cpp:131-160): cameras' translations in green, then points;
+    large enough (> 65536 lines) for the multi-threaded path, with values that round at the fourth decimal."""
+    pr = synth.make_problem(6, 70000, 150000, seed=10)
+    pr["pts"][:5] = [[0.00005, -0.00005, 1e9], [123456.78905, -0.99995, 0.5], [1e-9, -1e-9, 0.0], [2.5, -2.5, 1.00004999], [9.99995, 0.12345, -7.0]]
+    path = str(tmp_path / "problem-6-70000-pre.txt")
+    synth.write_bal(path, pr)
+    ply = str(tmp_path / "out.ply")
+    out = subprocess.run([CHECK, "--ply", path, ply], capture_output=True, text=True, timeout=120, cwd=str(tmp_path),
+                         env=dict(os.environ, BA_SIGMA_CAM="0", BA_SIGMA_X="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = out.stdout.split("\n")
+    n_cam, n_pt = map(int, lines[0].split())
+    vals = [[float.fromhex(t) for t in l.split()] for l in lines[1:1 + n_cam + n_pt]]
+    got = open(ply).read().split("\n")
+    assert got[:10] == ["ply", "format ascii 1.0", "element vertex %d" % (n_cam + n_pt), "property float x", "property float y",
+                        "property float z", "property uchar red", "property uchar green", "property uchar blue", "end_header"]
+    body = got[10:10 + n_cam + n_pt]
+    assert len(body) == n_cam + n_pt and got[10 + n_cam + n_pt:] == [""]
+    for i, (v, line) in enumerate(zip(vals, body)):
+        color = "0 255 0" if i < n_cam else line.split(" ", 3)[3]
+        assert line == "%.4f %.4f %.4f %s" % (v[0], v[1], v[2], color), (i, line, v)
