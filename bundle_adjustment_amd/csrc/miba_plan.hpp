@@ -205,107 +205,185 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   // first-fit-decreasing into 64-slot wavelets (a point never straddles a wavelet): little padding, and points
   // of similar length share a wavelet, which keeps the segmented scans of the kernels short.  Points are
   // renumbered in layout order.
-  std::vector<int32_t> new_orig;   // layout-order point -> caller's point id
-  new_orig.reserve(n_act);
-  P.pt_first.assign(n_act, 0);
-  P.pt_count.assign(n_act, 0);
-  std::vector<int32_t> stamp(n_cam, -1), slot_of(n_cam, 0);
-  int64_t slots = 0;
-  auto pad_to = [&](int64_t mult) {
-    while (slots % mult) { P.idx.push_back(-1); P.ocam.push_back(0); P.slot_orig.push_back(-1); ++slots; }
+  // Tiles are independent of each other, so contiguous ranges of tiles (balanced by observation count) are laid
+  // out by worker threads into buffers of their own with range-relative offsets, then copied to their final
+  // places (every tile is a whole number of chunks, so the ranges concatenate).
+  struct Part {
+    std::vector<Tile> tiles;
+    std::vector<Group> groups;
+    std::vector<int32_t> idx, ocam, tile_cams, new_orig, pt_first, pt_count;
+    std::vector<int64_t> slot_orig;
+    int64_t slots = 0;
   };
-  std::vector<int32_t> order, bin_free, bin_of;
-  std::vector<std::vector<int32_t>> bins;
-  for (size_t ti = 0; ti < spans.size(); ++ti) {
-    const Span sp = spans[ti];
-    Tile T{};
-    T.grp0 = (int32_t)P.groups.size();
-    T.cam0 = (int32_t)P.tile_cams.size();
-    T.giant = sp.giant;
-    T.slot0 = (int32_t)slots;
-    if (sp.giant) {
-      // one camera slot (= slab row) per observation, no LDS accumulation
-      const int32_t s = sp.s0;
-      const int64_t a = off[s], b = off[s + 1];
-      const int32_t L = (int32_t)(b - a);
-      const int32_t np = (int32_t)new_orig.size();
-      Group G{};
-      G.chunk0 = (int32_t)(slots / kChunk);
-      G.nchunk = (L + kChunk - 1) / kChunk;
-      G.pt0 = np; G.npt = 1;
-      P.pt_first[np] = (int32_t)slots;
-      P.pt_count[np] = L;
-      new_orig.push_back(P.pt_orig[s]);
-      for (int64_t j = a; j < b; ++j) {
-        const int64_t i = obs_sorted[j];
-        P.idx.push_back(0);
-        P.ocam.push_back(obs_cam[i]);
-        P.slot_orig.push_back(i);
-        P.tile_cams.push_back(obs_cam[i]);
-        ++slots;
-      }
-      pad_to(kChunk);
-      T.ncs = L;
-      P.groups.push_back(G);
-      T.ngrp = 1;
-    } else {
-      const int32_t np_t = sp.s1 - sp.s0;
-      order.resize(np_t);
-      for (int32_t k = 0; k < np_t; ++k) order[k] = sp.s0 + k;
-      std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
-      bins.clear(); bin_free.clear();
-      size_t first_open = 0;   // bins before it are full
-      for (int32_t s : order) {
-        const int32_t L = (int32_t)(off[s + 1] - off[s]);
-        size_t bsel = bins.size();
-        for (size_t bi = first_open; bi < bins.size(); ++bi)
-          if (bin_free[bi] >= L) { bsel = bi; break; }
-        if (bsel == bins.size()) { bins.emplace_back(); bin_free.push_back(kWave); }
-        bins[bsel].push_back(s);
-        bin_free[bsel] -= L;
-        while (first_open < bins.size() && bin_free[first_open] == 0) ++first_open;
-      }
-      const int32_t tid = (int32_t)ti;
-      for (size_t b0 = 0; b0 < bins.size(); b0 += 4) {
+  auto layout_range = [&](size_t t_begin, size_t t_end, Part& Q) {
+    std::vector<int32_t> stamp(n_cam, -1), slot_of(n_cam, 0);
+    std::vector<int32_t> order, bin_free;
+    std::vector<std::vector<int32_t>> bins;
+    int64_t& slots = Q.slots;
+    auto pad_to = [&](int64_t mult) {
+      while (slots % mult) { Q.idx.push_back(-1); Q.ocam.push_back(0); Q.slot_orig.push_back(-1); ++slots; }
+    };
+    for (size_t ti = t_begin; ti < t_end; ++ti) {
+      const Span sp = spans[ti];
+      Tile T{};
+      T.grp0 = (int32_t)Q.groups.size();
+      T.cam0 = (int32_t)Q.tile_cams.size();
+      T.giant = sp.giant;
+      T.slot0 = (int32_t)slots;
+      if (sp.giant) {
+        // one camera slot (= slab row) per observation, no LDS accumulation
+        const int32_t s = sp.s0;
+        const int64_t a = off[s], b = off[s + 1];
+        const int32_t L = (int32_t)(b - a);
+        const int32_t np = (int32_t)Q.new_orig.size();
         Group G{};
         G.chunk0 = (int32_t)(slots / kChunk);
-        G.nchunk = 1;
-        G.pt0 = (int32_t)new_orig.size();
-        for (size_t bi = b0; bi < std::min(b0 + 4, bins.size()); ++bi) {
-          for (int32_t s : bins[bi]) {
-            const int64_t a = off[s], b = off[s + 1];
-            const int32_t L = (int32_t)(b - a);
-            const int32_t np = (int32_t)new_orig.size();
-            const int32_t pl = np - G.pt0;
-            P.pt_first[np] = (int32_t)slots;
-            P.pt_count[np] = L;
-            new_orig.push_back(P.pt_orig[s]);
-            for (int64_t j = a; j < b; ++j) {
-              const int64_t i = obs_sorted[j];
-              const int32_t c = obs_cam[i];
-              if (stamp[c] != tid) {
-                stamp[c] = tid;
-                slot_of[c] = T.ncs++;
-                P.tile_cams.push_back(c);
-              }
-              // point-in-chunk | camera-slot-in-tile << 8 | position in the point's run << 16 | run length << 23
-              P.idx.push_back(pl | (slot_of[c] << 8) | ((int32_t)(j - a) << 16) | (L << 23));
-              P.ocam.push_back(c);
-              P.slot_orig.push_back(i);
-              ++slots;
-            }
-            G.npt++;
-          }
-          pad_to(kWave);
+        G.nchunk = (L + kChunk - 1) / kChunk;
+        G.pt0 = np; G.npt = 1;
+        Q.pt_first.push_back((int32_t)slots);
+        Q.pt_count.push_back(L);
+        Q.new_orig.push_back(P.pt_orig[s]);
+        for (int64_t j = a; j < b; ++j) {
+          const int64_t i = obs_sorted[j];
+          Q.idx.push_back(0);
+          Q.ocam.push_back(obs_cam[i]);
+          Q.slot_orig.push_back(i);
+          Q.tile_cams.push_back(obs_cam[i]);
+          ++slots;
         }
         pad_to(kChunk);
-        P.groups.push_back(G);
-        T.ngrp++;
+        T.ncs = L;
+        Q.groups.push_back(G);
+        T.ngrp = 1;
+      } else {
+        const int32_t np_t = sp.s1 - sp.s0;
+        order.resize(np_t);
+        for (int32_t k = 0; k < np_t; ++k) order[k] = sp.s0 + k;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
+        bins.clear(); bin_free.clear();
+        size_t first_open = 0;   // bins before it are full
+        for (int32_t s : order) {
+          const int32_t L = (int32_t)(off[s + 1] - off[s]);
+          size_t bsel = bins.size();
+          for (size_t bi = first_open; bi < bins.size(); ++bi)
+            if (bin_free[bi] >= L) { bsel = bi; break; }
+          if (bsel == bins.size()) { bins.emplace_back(); bin_free.push_back(kWave); }
+          bins[bsel].push_back(s);
+          bin_free[bsel] -= L;
+          while (first_open < bins.size() && bin_free[first_open] == 0) ++first_open;
+        }
+        const int32_t tid = (int32_t)ti;
+        for (size_t b0 = 0; b0 < bins.size(); b0 += 4) {
+          Group G{};
+          G.chunk0 = (int32_t)(slots / kChunk);
+          G.nchunk = 1;
+          G.pt0 = (int32_t)Q.new_orig.size();
+          for (size_t bi = b0; bi < std::min(b0 + 4, bins.size()); ++bi) {
+            for (int32_t s : bins[bi]) {
+              const int64_t a = off[s], b = off[s + 1];
+              const int32_t L = (int32_t)(b - a);
+              const int32_t np = (int32_t)Q.new_orig.size();
+              const int32_t pl = np - G.pt0;
+              Q.pt_first.push_back((int32_t)slots);
+              Q.pt_count.push_back(L);
+              Q.new_orig.push_back(P.pt_orig[s]);
+              for (int64_t j = a; j < b; ++j) {
+                const int64_t i = obs_sorted[j];
+                const int32_t c = obs_cam[i];
+                if (stamp[c] != tid) {
+                  stamp[c] = tid;
+                  slot_of[c] = T.ncs++;
+                  Q.tile_cams.push_back(c);
+                }
+                // point-in-chunk | camera-slot-in-tile << 8 | position in the point's run << 16 | run length << 23
+                Q.idx.push_back(pl | (slot_of[c] << 8) | ((int32_t)(j - a) << 16) | (L << 23));
+                Q.ocam.push_back(c);
+                Q.slot_orig.push_back(i);
+                ++slots;
+              }
+              G.npt++;
+            }
+            pad_to(kWave);
+          }
+          pad_to(kChunk);
+          Q.groups.push_back(G);
+          T.ngrp++;
+        }
       }
+      T.nslot = (int32_t)(slots - T.slot0);
+      Q.tiles.push_back(T);
     }
-    T.nslot = (int32_t)(slots - T.slot0);
-    P.tiles.push_back(T);
-    if (slots >= (int64_t)INT32_MAX - kChunk) return -6;
+  };
+  // ranges of tiles with about equal observation counts
+  unsigned n_part = std::thread::hardware_concurrency();
+  if (const char* e = getenv("MIBA_PLAN_THREADS")) n_part = (unsigned)atoi(e);
+  if (n_part < 1) n_part = 1;
+  if (n_part > 16) n_part = 16;
+  if (off[n_act] < (1 << 18) || spans.size() < 4 * (size_t)n_part) n_part = 1;
+  std::vector<size_t> cut(n_part + 1, spans.size());
+  cut[0] = 0;
+  {
+    size_t ti = 0;
+    for (unsigned k = 1; k < n_part; ++k) {
+      const int64_t target = off[n_act] * (int64_t)k / n_part;
+      while (ti < spans.size() && off[spans[ti].s0] < target) ++ti;
+      cut[k] = ti;
+    }
+  }
+  std::vector<Part> parts(n_part);
+  {
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < n_part; ++k) th.emplace_back([&, k] { layout_range(cut[k], cut[k + 1], parts[k]); });
+    layout_range(cut[0], cut[1], parts[0]);
+    for (auto& x : th) x.join();
+  }
+  // offsets of every range in the concatenated arrays
+  std::vector<int64_t> o_slot(n_part + 1, 0), o_grp(n_part + 1, 0), o_cam(n_part + 1, 0), o_pt(n_part + 1, 0), o_tile(n_part + 1, 0);
+  for (unsigned k = 0; k < n_part; ++k) {
+    o_slot[k + 1] = o_slot[k] + parts[k].slots;
+    o_grp[k + 1] = o_grp[k] + (int64_t)parts[k].groups.size();
+    o_cam[k + 1] = o_cam[k] + (int64_t)parts[k].tile_cams.size();
+    o_pt[k + 1] = o_pt[k] + (int64_t)parts[k].new_orig.size();
+    o_tile[k + 1] = o_tile[k] + (int64_t)parts[k].tiles.size();
+  }
+  const int64_t slots = o_slot[n_part];
+  if (slots >= (int64_t)INT32_MAX - kChunk || o_cam[n_part] >= INT32_MAX) return -6;   // slot and row indices are int32 on the device
+  std::vector<int32_t> new_orig((size_t)o_pt[n_part]);   // layout-order point -> caller's point id
+  P.pt_first.assign((size_t)o_pt[n_part], 0);
+  P.pt_count.assign((size_t)o_pt[n_part], 0);
+  P.idx.resize((size_t)slots); P.ocam.resize((size_t)slots); P.slot_orig.resize((size_t)slots);
+  P.tile_cams.resize((size_t)o_cam[n_part]);
+  P.groups.resize((size_t)o_grp[n_part]);
+  P.tiles.resize((size_t)o_tile[n_part]);
+  {
+    auto place = [&](unsigned k) {
+      Part& Q = parts[k];
+      std::copy(Q.idx.begin(), Q.idx.end(), P.idx.begin() + o_slot[k]);
+      std::copy(Q.ocam.begin(), Q.ocam.end(), P.ocam.begin() + o_slot[k]);
+      std::copy(Q.slot_orig.begin(), Q.slot_orig.end(), P.slot_orig.begin() + o_slot[k]);
+      std::copy(Q.tile_cams.begin(), Q.tile_cams.end(), P.tile_cams.begin() + o_cam[k]);
+      std::copy(Q.new_orig.begin(), Q.new_orig.end(), new_orig.begin() + o_pt[k]);
+      std::copy(Q.pt_count.begin(), Q.pt_count.end(), P.pt_count.begin() + o_pt[k]);
+      for (size_t i = 0; i < Q.pt_first.size(); ++i) P.pt_first[(size_t)o_pt[k] + i] = Q.pt_first[i] + (int32_t)o_slot[k];
+      for (size_t i = 0; i < Q.groups.size(); ++i) {
+        Group G = Q.groups[i];
+        G.chunk0 += (int32_t)(o_slot[k] / kChunk);
+        G.pt0 += (int32_t)o_pt[k];
+        P.groups[(size_t)o_grp[k] + i] = G;
+      }
+      for (size_t i = 0; i < Q.tiles.size(); ++i) {
+        Tile T = Q.tiles[i];
+        T.grp0 += (int32_t)o_grp[k];
+        T.cam0 += (int32_t)o_cam[k];
+        T.slot0 += (int32_t)o_slot[k];
+        P.tiles[(size_t)o_tile[k] + i] = T;
+      }
+      Q = Part();
+    };
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < n_part; ++k) th.emplace_back(place, k);
+    place(0);
+    for (auto& x : th) x.join();
   }
   lap("phase 2 (layout)");
   if (slots >= (int64_t)INT32_MAX - kChunk) return -6;   // slot indices are int32 on the device

@@ -132,3 +132,23 @@ def test_point_sharding_world2_gloo(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_plan_threaded_layout_equals_serial():
+    """Phase 2 of the tiler lays ranges of tiles out on worker threads (problems above 2^18 observations): the plan
+    must not depend on the number of threads."""
+    pr = synth.make_problem(300, 60000, 330000, seed=13, shuffle_obs=True)
+    oc, op, oxy = pr["obs_cam"], pr["obs_pt"], pr["obs_xy"]
+    res = []
+    for thr in ("1", "2", "7"):
+        os.environ["MIBA_PLAN_THREADS"] = thr
+        try:
+            info = miba.plan_shards(300, 60000, oc, op, oxy, 8)
+            owner = miba.plan_point_owner(300, 60000, oc, op, oxy, 8)
+        finally:
+            os.environ.pop("MIBA_PLAN_THREADS", None)
+        res.append((info, owner))
+    assert res[0][0]["n_tiles"] >= 100
+    for info, owner in res[1:]:
+        assert info == res[0][0]
+        assert np.array_equal(owner, res[0][1])
