@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--preconditioner", choices=["jacobi", "schur_jacobi"], default="jacobi",
                     help="PCG preconditioner; jacobi is Ceres' default and what the reference runs with")
-    ap.add_argument("--ttt", type=int, default=0, help="also report time-to-cost-tolerance over at most this many LM iterations")
+    ap.add_argument("--ttt", type=int, default=80, help="also report time-to-cost-tolerance over at most this many LM iterations")
     args = ap.parse_args()
 
     import ctypes
