@@ -4,6 +4,9 @@
 // HIP Levenberg-Marquardt / implicit-Schur PCG through the C ABI (include/miba.h) instead of
 // ceres::Solve (:108).  No per-observation cost-function objects are created on this path.
 #include <charconv>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -80,7 +83,8 @@ struct PhaseTimer {
 BundleAdjustment::BundleAdjustment(Dataloader *dataset, ceres::Solver::Options options)
         : dataset(dataset),
           options(options),
-          problem(nullptr) {
+          problem(nullptr),
+          plyQueue(nullptr) {
 
     PhaseTimer pt("constructor");
     callback = new MeshWriterCallback(this, ceres::LinearSolverTypeToString(options.linear_solver_type));
@@ -93,7 +97,10 @@ BundleAdjustment::BundleAdjustment(Dataloader *dataset, ceres::Solver::Options o
     dataset->initialize(R, T, intrinsics, X);
 }
 
+static void ply_queue_close(PlyQueue *q);   // drains and deletes (defined with the queue, below)
+
 BundleAdjustment::~BundleAdjustment() {
+    ply_queue_close(plyQueue);
     if (problem) miba_destroy(problem);
     delete[] R;
     delete[] T;
@@ -171,7 +178,8 @@ void BundleAdjustment::solve() {
     (*callback)(sum);
 
     options.update_state_every_iteration = true;
-    if (static_cast<MeshWriterCallback *>(callback)->isEnabled()) options.callbacks.push_back(callback);
+    const bool mesh_pushed = static_cast<MeshWriterCallback *>(callback)->isEnabled();
+    if (mesh_pushed) options.callbacks.push_back(callback);
 
     miba_options o;
     miba_default_options(&o);
@@ -205,7 +213,8 @@ void BundleAdjustment::solve() {
     miba_summary ms;
     check(miba_solve(problem, &o, iteration_trampoline, &ctx, &ms), problem, "miba_solve");
     check(miba_get_state(problem, R, T, intrinsics, X), problem, "miba_get_state");
-    options.callbacks.pop_back();
+    if (mesh_pushed) options.callbacks.pop_back();
+    flushPlyWrites();   // the per-iteration dumps queued by the mesh callback are on disk when solve() returns
 
     summary.termination_type = (ceres::TerminationType) ms.termination_type;
     summary.message = ms.message;
@@ -254,10 +263,13 @@ double *BundleAdjustment::getPoint(size_t pointIndex) {
     return &X[pointIndex * 3];
 }
 
-void BundleAdjustment::WriteToPLYFile(std::string filename) {
-    PhaseTimer pt("WriteToPLYFile");
-    // ASCII PLY: cameras (translation vector, green) then points, 4 decimals
-    // (src/BundleAdjustment.cpp:131-160)
+namespace {
+
+// ASCII PLY: cameras (translation vector, green) then points, 4 decimals (src/BundleAdjustment.cpp:131-160).
+// Same text as fprintf("%.4f %.4f %.4f %d %d %d\n") line by line (std::to_chars in fixed notation rounds the way
+// printf does), formatted by worker threads into per-range buffers and written in order: a Final-13682 dump is
+// 4.5 M lines, and the reference writes one per LM iteration.
+void write_ply(const std::string &filename, int n_frames, int n_points, const double *T, const double *X, const Dataloader *dataset) {
     FILE *of = fopen(filename.c_str(), "w");
     if (!of) throw std::runtime_error("cannot open " + filename);
     fprintf(of, "ply"
@@ -269,12 +281,7 @@ void BundleAdjustment::WriteToPLYFile(std::string filename) {
                 "\nproperty uchar red"
                 "\nproperty uchar green"
                 "\nproperty uchar blue"
-                "\nend_header\n", this->dataset->getNumPoints() + this->dataset->getNumFrames());
-
-    // Same text as fprintf("%.4f %.4f %.4f %d %d %d\n") line by line (std::to_chars in fixed notation rounds the way
-    // printf does), formatted by worker threads into per-range buffers and written in order: a Final-13682 dump is
-    // 4.5 M lines, and the reference writes one per LM iteration.
-    const int n_frames = this->dataset->getNumFrames(), n_points = this->dataset->getNumPoints();
+                "\nend_header\n", n_points + n_frames);
     const long long n_lines = (long long) n_frames + n_points;
     unsigned n_thr = std::thread::hardware_concurrency();
     if (n_thr < 1) n_thr = 1;
@@ -297,13 +304,13 @@ void BundleAdjustment::WriteToPLYFile(std::string filename) {
         out.reserve((size_t) (b - a) * 40);
         for (long long l = a; l < b; ++l) {
             if (l < n_frames) {
-                const double *cam = getTranslation((size_t) l);
+                const double *cam = T + 3 * (size_t) l;
                 put_fixed4(out, cam[0]); out += ' '; put_fixed4(out, cam[1]); out += ' '; put_fixed4(out, cam[2]);
                 out += " 0 255 0\n";
             } else {
                 const int i = (int) (l - n_frames);
-                const double *point = getPoint((size_t) i);
-                Eigen::Vector3i bgr = this->dataset->getPointColor(i);
+                const double *point = X + 3 * (size_t) i;
+                Eigen::Vector3i bgr = dataset->getPointColor(i);
                 if (!std::isnan(point[0])) {
                     put_fixed4(out, point[0]); out += ' '; put_fixed4(out, point[1]); out += ' '; put_fixed4(out, point[2]);
                 } else {
@@ -321,4 +328,85 @@ void BundleAdjustment::WriteToPLYFile(std::string filename) {
     }
     for (unsigned t = 0; t < n_thr; ++t) fwrite(chunk[t].data(), 1, chunk[t].size(), of);
     fclose(of);
+}
+
+}  // namespace
+
+// Per-iteration dumps off the solver's critical path: the mesh callback hands a snapshot of the
+// translations and points to one writer thread and the LM loop goes on; at most two snapshots wait (a third caller
+// blocks), files are written in order, and solve() / the destructor wait for the queue to drain.
+struct PlyQueue {
+    struct Job { std::string name; std::vector<double> T, X; };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    bool busy = false, stop = false;
+    std::string error;
+    int n_frames, n_points;
+    const Dataloader *dataset;
+    std::thread worker;
+    PlyQueue(int nf, int np, const Dataloader *d) : n_frames(nf), n_points(np), dataset(d), worker([this] { run(); }) {}
+    ~PlyQueue() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        worker.join();
+    }
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                j = std::move(jobs.front());
+                jobs.pop_front();
+                busy = true;
+            }
+            cv.notify_all();
+            try { write_ply(j.name, n_frames, n_points, j.T.data(), j.X.data(), dataset); }
+            catch (const std::exception &e) { std::lock_guard<std::mutex> l(m); if (error.empty()) error = e.what(); }
+            { std::lock_guard<std::mutex> l(m); busy = false; }
+            cv.notify_all();
+        }
+    }
+    void push(Job &&j) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return jobs.size() < 2; });
+        jobs.push_back(std::move(j));
+        l.unlock();
+        cv.notify_all();
+    }
+    void drain() {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return jobs.empty() && !busy; });
+        if (!error.empty()) { std::string e = error; error.clear(); throw std::runtime_error(e); }
+    }
+};
+
+static void ply_queue_close(PlyQueue *q) {
+    if (!q) return;
+    try { q->drain(); } catch (const std::exception &e) { fprintf(stderr, "PLY writer: %s\n", e.what()); }
+    delete q;
+}
+
+void BundleAdjustment::WriteToPLYFile(std::string filename) {
+    PhaseTimer pt("WriteToPLYFile");
+    flushPlyWrites();   // keep files in the order they were asked for
+    write_ply(filename, this->dataset->getNumFrames(), this->dataset->getNumPoints(), T, X, this->dataset);
+}
+
+void BundleAdjustment::WriteToPLYFileAsync(std::string filename) {
+    const char *e = getenv("BA_ASYNC_PLY");
+    if (e && e[0] == '0') { WriteToPLYFile(filename); return; }
+    const int nf = this->dataset->getNumFrames(), np = this->dataset->getNumPoints();
+    if (!plyQueue) plyQueue = new PlyQueue(nf, np, this->dataset);
+    PlyQueue::Job j;
+    j.name = std::move(filename);
+    j.T.assign(T, T + 3 * (size_t) nf);
+    j.X.assign(X, X + 3 * (size_t) np);
+    plyQueue->push(std::move(j));
+}
+
+void BundleAdjustment::flushPlyWrites() {
+    if (plyQueue) plyQueue->drain();
 }

@@ -27,7 +27,7 @@ public:
         if(enabled && summary.iteration % 1 == 0) {
             char name[256];
             snprintf(name, sizeof(name), "mesh_%s_%d.ply", prefix.c_str(), summary.iteration);
-            ba->WriteToPLYFile(name);
+            ba->WriteToPLYFileAsync(name);   // snapshot now, text later: the LM loop does not wait for the file
         }
         return ceres::SOLVER_CONTINUE;
     }

@@ -10,6 +10,7 @@
 
 class MeshWriterCallback;
 struct miba_handle_s;
+struct PlyQueue;
 
 class BundleAdjustment {
 public:
@@ -25,6 +26,11 @@ public:
     double* getPoint(size_t pointIndex);
 
     void WriteToPLYFile(std::string filename);
+    // Not in the reference: the same file written by a background thread from a snapshot of the current state (used by
+    // the per-iteration mesh callback; BA_ASYNC_PLY=0 makes it synchronous).  flushPlyWrites() waits for the queue;
+    // solve(), WriteToPLYFile() and the destructor call it.
+    void WriteToPLYFileAsync(std::string filename);
+    void flushPlyWrites();
 
     Dataloader* dataset;
 
@@ -41,4 +47,5 @@ private:
     double *T;
     double *intrinsics;
     MeshWriterCallback *callback;
+    PlyQueue *plyQueue;
 };

@@ -101,6 +101,13 @@ def test_app_main_end_to_end(tmp_path, oracle):
     head = open(tmp_path / "constrainTransReal.ply").read().split("\n")
     assert head[0] == "ply" and head[2] == "element vertex %d" % (600 + 20)
     assert head[10].endswith(" 0 255 0") and "Solver Summary" in out.stdout
+    # one dump per iteration record (written by the background PLY thread, all on disk when solve() has returned),
+    # every one complete; the dump of the last iteration holds the final state
+    n_it = int(m.group(2))
+    dumps = sorted(f for f in os.listdir(tmp_path) if f.startswith("mesh_SPARSE_SCHUR_"))
+    assert len(dumps) >= n_it and all(len(open(tmp_path / f).read().split("\n")) == 10 + 620 + 1 for f in dumps)
+    last = max(int(f[len("mesh_SPARSE_SCHUR_"):-4]) for f in dumps)
+    assert open(tmp_path / ("mesh_SPARSE_SCHUR_%d.ply" % last)).read() == open(tmp_path / "constrainTransReal.ply").read()
     # a factorisation-based solver type on a small problem is served by the device Cholesky, and the report says so
     if os.environ.get("MIBA_MF", "1") != "0" and os.environ.get("MIBA_DENSE", "1") != "0":
         assert "blocked Cholesky on the device" in out.stdout, out.stdout[-2000:]

@@ -16,7 +16,7 @@ t = time.time()
 synth.write_bal(path, pr)
 print("wrote %.1f MB in %.1f s" % (os.path.getsize(path) / 1e6, time.time() - t), flush=True)
 exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'app', 'ba_main')
-env = dict(os.environ, BA_ITERATION_PLY="0", BA_SIGMA_CAM=os.environ.get("BA_SIGMA_CAM", "0.001"),
+env = dict(os.environ, BA_ITERATION_PLY=os.environ.get("BA_ITERATION_PLY", "0"), BA_SIGMA_CAM=os.environ.get("BA_SIGMA_CAM", "0.001"),
            BA_SIGMA_X=os.environ.get("BA_SIGMA_X", "0.05"), BA_LOADER_DEBUG="1")
 t = time.time()
 out = subprocess.run([exe, path, solver, iters], capture_output=True, text=True, cwd=d, env=env)
@@ -26,3 +26,5 @@ lines = out.stdout.split("\n")
 keep = [l for l in lines if re.search(r"FINAL_COST|Solver Summary|Cost:|Initial|Final|Termination|iterations|Time|Linear solver|Minimizer|Residual|Jacobian|Total|Creating|Solving|Invalid", l)]
 print("\n".join(keep[-60:]))
 os.remove(path)
+import shutil
+shutil.rmtree(d, ignore_errors=True)
