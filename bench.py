@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--eta", type=float, default=0.1)
     ap.add_argument("--check-every", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-states", action="store_true", help="skip the two extra initial states of SURVEY 8(d)")
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--preconditioner", choices=["jacobi", "schur_jacobi"], default="jacobi",
                     help="PCG preconditioner; jacobi is Ceres' default and what the reference runs with")
@@ -276,6 +277,28 @@ def main():
                                     "final_cost": cstar, "iterations_run": summ2["num_iterations"],
                                     "termination": summ2["message"], "total_seconds": summ2["total_time_in_seconds"],
                                     "reference_cost": "final cost of this run (own C*, max %d iterations)" % args.ttt}
+
+    if not args.no_other_states:
+        # SURVEY 8(d) also asks for the reference loader's own noise, sigma = (0.01, 2.0) (src/BalDataloader.cpp:132-133),
+        # and for the noise-free start (observation noise only): 20 LM iterations each with the same options, tolerances
+        # off.  `value` above stays on the --sigma-cam / --sigma-x start.
+        other = {}
+        for label, (sc_, sx_) in (("reference_sigma_0.01_2.0", (0.01, 2.0)), ("ground_truth_start", (0.0, 0.0))):
+            c1, p1 = synth.perturb(pr, sc_, sx_, seed=seed + 1)
+            solver.set_state(c1, p1)
+            o3 = miba.default_options(max_num_iterations=20, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
+                                      function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
+                                      pcg_check_every=args.check_every, preconditioner_type=precond)
+            sync()
+            its3, summ3 = solver.solve(o3)
+            sync()
+            n3 = max(1, len(its3) - 1)
+            other[label] = {"lm_iterations": n3, "lm_iterations_per_s": n3 / max(summ3["total_time_in_seconds"], 1e-12),
+                            "pcg_iterations": summ3["num_linear_solver_iterations"],
+                            "successful_steps": summ3["num_successful_steps"],
+                            "cost_first": its3[0]["cost"], "cost_last": summ3["final_cost"]}
+        out["other_initial_states"] = other
+        solver.set_state(cams0, pts0)
 
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (a port, oracle/ba_oracle.c) on the host cores, same problem and
