@@ -310,7 +310,7 @@ int eval_jac(miba_handle h, const double* cam, const double* X, bool scaled) {
   return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
 }
 
-int eval_cost(miba_handle h, const double* cam, const double* X) {
+int eval_cost(miba_handle h, const double* cam, const double* X, bool reduce = true) {
   // candidate state: its camera table must not disturb the table of the current state (K3-mf reads it)
   int rc = launch_cam_tables(h, cam, true);
   if (rc) return rc;
@@ -326,7 +326,7 @@ int eval_cost(miba_handle h, const double* cam, const double* X) {
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
   HIPCHK(h, hipGetLastError());
-  return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
+  return reduce ? allreduce(h, h->d_sum + S_COST, 1, ncclSum) : MIBA_OK;
 }
 
 constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 + 4) * sizeof(double);
@@ -334,7 +334,7 @@ constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 +
 // K2 + camera reductions + camera blocks; fills Cinv, gp, Minv, Dc2, rhs and the gradient norms
 // K2-mf over all tiles of this shard (camera tables of the current state must be in d_ct / d_cm):
 // per-point blocks, raw camera slab rows, cost -> d_sum[S_COST] (all-reduced)
-int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want_diag) {
+int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want_diag, bool reduce_cost = true) {
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
 #define MIBA_INIT_ARGS(list)                                                                                              \
@@ -363,7 +363,7 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 1, 1, h->d_max + S_GMAX_P);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 2, 0, h->d_sum + S_G2_P);
   HIPCHK(h, hipGetLastError());
-  return allreduce(h, h->d_sum + S_COST, 1, ncclSum);
+  return reduce_cost ? allreduce(h, h->d_sum + S_COST, 1, ncclSum) : MIBA_OK;
 }
 
 // camera sums of K2: rows of the tile slab (stored-J / one-pass K2-mf) or of the segment slab (two-pass K2-mf)
@@ -379,8 +379,12 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   const double inv_r = 1.0 / radius;
   HIPCHK(h, hipMemsetAsync(&h->d_ctl->fail, 0, sizeof(int32_t), h->st));
   int rc;
+  // With several ranks the three scalars of this stage (cost, |g_p|^2, max |g_p|) ride in the unused 64th entry of
+  // the camera sums (cameras 0, 1 and 2 + rank: one slot per rank turns the max into a sum), so the stage costs ONE
+  // all-reduce instead of four.
+  const bool pack = h->use_mf && multi_rank(h) && h->n_cam >= 2 + h->cfg.world_size;
   if (h->use_mf) {
-    rc = mf_init_launch(h, inv_r, o, false);
+    rc = mf_init_launch(h, inv_r, o, false, !pack);
     if (rc) return rc;
   } else if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
@@ -391,8 +395,11 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   HIPCHK(h, hipGetLastError());
   rc = cam_reduce64(h, h->use_mf ? h->d_sc : (const double*)nullptr);
   if (rc) return rc;
+  if (pack) hipLaunchKernelGGL(k_pack_scalars, dim3(1), dim3(64), 0, h->st, h->d_camacc, h->d_sum, h->d_max, h->cfg.rank, 0, h->cfg.world_size);
   rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
   if (rc) return rc;
+  if (pack) hipLaunchKernelGGL(k_pack_scalars, dim3(1), dim3(64), 0, h->st, h->d_camacc, h->d_sum, h->d_max, h->cfg.rank, 1, h->cfg.world_size);
+  HIPCHK(h, hipGetLastError());
   const double* acc2 = nullptr;
   if (o->preconditioner_type == MIBA_PRECOND_SCHUR_JACOBI && o->linear_solver_type == MIBA_ITERATIVE_SCHUR) {
     // block diagonal of S itself: one more camera-major pass for sum G'WG (needs the point records K2 has just written)
@@ -428,6 +435,7 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 1, 0, h->d_sum + S_G2_P);
   }
   HIPCHK(h, hipGetLastError());
+  if (pack) return MIBA_OK;
   rc = allreduce(h, h->d_sum + S_G2_P, 1, ncclSum);
   if (rc) return rc;
   return allreduce(h, h->d_max + S_GMAX_P, 1, ncclMax);
@@ -727,7 +735,8 @@ int linear_solve(miba_handle h, const miba_options* o, int* n_it, int* status) {
 }
 
 // back-substitution, candidate state, model cost change, step / candidate norms
-int backsub_and_candidate(miba_handle h) {
+// reduce = false: the caller all-reduces S_MCC, S_DP2, S_XP2 itself (together with the candidate cost)
+int backsub_and_candidate(miba_handle h, bool reduce = true) {
   if (h->use_mf) {
     if (h->n_tiles) {
       Timed t(h, MIBA_K_BACKSUB);
@@ -750,8 +759,10 @@ int backsub_and_candidate(miba_handle h) {
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 1, 0, h->d_sum + S_DP2);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 2, 0, h->d_sum + S_XP2);
   HIPCHK(h, hipGetLastError());
-  int rc = allreduce(h, h->d_sum + S_MCC, 3, ncclSum);  // S_MCC, S_DP2, S_XP2 are adjacent
-  if (rc) return rc;
+  if (reduce) {
+    int rc = allreduce(h, h->d_sum + S_MCC, 3, ncclSum);  // S_MCC, S_DP2, S_XP2 are adjacent
+    if (rc) return rc;
+  }
   const int nb = 120;
   hipLaunchKernelGGL(k_cam_update, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_cam, h->d_sc, h->d_px, h->d_cam_active,
                      h->d_cam_cand, h->d_part_small);
@@ -1591,11 +1602,21 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
     if (rc) return rc;
     it.linear_solver_iterations = n_cg;
     S.num_linear_solver_iterations += n_cg;
-    rc = backsub_and_candidate(h);
+    // The candidate cost is evaluated before the model cost change has been looked at (the step is almost always
+    // valid): its partial sum sits next to those of the back-substitution, so one all-reduce of four scalars and one
+    // host read serve both.
+    rc = backsub_and_candidate(h, false);
+    if (rc) return rc;
+    t_linear += now_s() - tl;
+    const double tr = now_s();
+    rc = eval_cost(h, h->d_cam_cand, h->d_Xc, false);
+    if (rc) return rc;
+    static_assert(S_COST + 1 == S_MCC && S_MCC + 1 == S_DP2 && S_DP2 + 1 == S_XP2, "scalar slots must be adjacent");
+    rc = allreduce(h, h->d_sum + S_COST, 4, ncclSum);
     if (rc) return rc;
     rc = read_scalars(h);
     if (rc) return rc;
-    t_linear += now_s() - tl;
+    t_res += now_s() - tr;
     const double mcc = h->h_scal[S_MCC];
     const bool ls_failed = (cg_status == 2) || h->h_ctl->fail || !std::isfinite(mcc);
     it.model_cost_change = ls_failed ? 0.0 : mcc;
@@ -1620,12 +1641,6 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
       continue;
     }
     consecutive_invalid = 0;
-    const double tr = now_s();
-    rc = eval_cost(h, h->d_cam_cand, h->d_Xc);
-    if (rc) return rc;
-    rc = read_scalars(h);
-    if (rc) return rc;
-    t_res += now_s() - tr;
     double cand_cost = h->h_scal[S_COST];
     if (!std::isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     it.step_norm = sqrt(h->h_scal[S_DC2] + h->h_scal[S_DP2]);

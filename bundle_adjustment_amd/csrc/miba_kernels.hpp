@@ -819,6 +819,25 @@ __global__ __launch_bounds__(256) void k_cam_reduce64(int n_cam, const int32_t* 
   out[(size_t)kK2W * c + lane] = a0;
 }
 
+// Scalars of the Schur init in the unused 64th entry of the camera sums (multi-rank runs: one all-reduce for the
+// stage).  unpack = 0: local cost, |g_p|^2 and max |g_p| into cameras 0, 1 and 2 + rank; unpack = 1 (after the
+// all-reduce): totals back into the scalar slots, the max over the per-rank entries.
+__global__ void k_pack_scalars(double* __restrict__ acc, double* __restrict__ sum, double* __restrict__ mx, int rank, int unpack,
+                               int world) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!unpack) {
+    acc[(size_t)kK2W * 0 + 63] = sum[S_COST];
+    acc[(size_t)kK2W * 1 + 63] = sum[S_G2_P];
+    acc[(size_t)kK2W * (2 + rank) + 63] = mx[S_GMAX_P];
+  } else {
+    sum[S_COST] = acc[(size_t)kK2W * 0 + 63];
+    sum[S_G2_P] = acc[(size_t)kK2W * 1 + 63];
+    double m = 0.0;
+    for (int r = 0; r < world; ++r) m = fmax(m, acc[(size_t)kK2W * (2 + r) + 63]);
+    mx[S_GMAX_P] = m;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Camera blocks: B = F'F + D^2 -> M^-1 (9x9 Cholesky inverse), rhs, unscaled gradient norms.
 // acc[c][64] = {F'F upper 45, rhs 9, F'r 9}.  One thread per camera.
