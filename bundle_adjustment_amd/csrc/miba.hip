@@ -699,7 +699,7 @@ int dense_factor_solve(miba_handle h, double* A, int N, double* Ldiag, const dou
   for (int k = 0; k < nb; ++k) {
     const int k0 = k * kNB;
     const int below = nb - 1 - k;                        // 64-column tiles to the right
-    hipLaunchKernelGGL(k_chol_panel, dim3((below + 1 + 3) / 4), dim3(256), 0, h->st, A, N, NR, k0, Ldiag + (size_t)k * kLdiag, (int*)d_flag);
+    hipLaunchKernelGGL(k_chol_panel, dim3(below + 1), dim3(kNB), 0, h->st, A, N, NR, k0, Ldiag + (size_t)k * kLdiag, (int*)d_flag);
     if (below > 0) hipLaunchKernelGGL(k_chol_update, dim3(below, below + 1), dim3(256), 0, h->st, A, N, k0);
   }
   for (int k = nb - 1; k >= 0; --k) {

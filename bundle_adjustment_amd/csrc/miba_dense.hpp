@@ -365,23 +365,24 @@ __device__ __forceinline__ bool chol_diag_wave(const double* __restrict__ S, int
   return bad;
 }
 
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int N, int NR, int k0, double* __restrict__ Ldiag /*[kLdiag]*/,
-                                                    int* __restrict__ flag) {
+// One wave per workgroup: 64 rows of the panel each.  (Four waves sharing one factor in LDS were slower: the
+// wave-uniform reads cost full LDS return bandwidth per wave, and one wave per CU has the LDS pipe to itself.)
+__global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ S, int N, int NR, int k0, double* __restrict__ Ldiag /*[kLdiag]*/,
+                                                   int* __restrict__ flag) {
   __shared__ __align__(16) double Lt[kNB * kLs];   // Lt[k][c] = L[c][k]
   __shared__ double Lr[kNB];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (wv == 0) {
+  const int lane = threadIdx.x;
+  {
     const bool bad = chol_diag_wave(S, N, k0, lane, Lt, Lr);
     if (bad && blockIdx.x == 0 && lane == 0) *flag = 1;
   }
-  __syncthreads();
   if (blockIdx.x == 0) {
-    for (int i = tid; i < kNB * kNB; i += 256) Ldiag[i] = Lt[(i & 63) * kLs + (i >> 6)];
-    if (tid < kNB) Ldiag[kNB * kNB + tid] = Lr[tid];
+    for (int i = lane; i < kNB * kNB; i += kNB) Ldiag[i] = Lt[(i & 63) * kLs + (i >> 6)];
+    Ldiag[kNB * kNB + lane] = Lr[lane];
   }
   // my row of the panel: x L11' = a, right-looking forward substitution (each solved entry updates all the later
   // ones: independent FMAs), the factor read as wave-uniform LDS operands
-  const int r = k0 + kNB + ((int)blockIdx.x * 4 + wv) * kNB + lane;
+  const int r = k0 + kNB + (int)blockIdx.x * kNB + lane;
   if (r >= NR) return;
   double* row = S + (size_t)r * N + k0;
   double x[kNB];
