@@ -55,6 +55,14 @@ def test_ranks_agree_with_single_rank(single, world, tmp_path):
     check(launch(world, tmp_path), single, world)
 
 
+def test_ranks_agree_with_single_rank_empty_shards(single, tmp_path):
+    """Eight ranks for a problem of seven default-size tiles: at least one rank owns nothing and still has to take
+    part in every reduction with zeros."""
+    ranks = launch(8, tmp_path)
+    assert any(np.abs(o["y_pt"]).sum() == 0.0 for o in ranks)
+    check(ranks, single, 8)
+
+
 def test_ranks_agree_with_single_rank_giant_points(single_giant, tmp_path):
     """One-chunk tiles (so that four ranks all own tiles) and a point with more than 64 observations."""
     check(launch(4, tmp_path, "giant", {"MIBA_TILE_CHUNKS": "1"}), single_giant, 4)
