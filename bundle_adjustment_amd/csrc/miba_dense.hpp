@@ -327,14 +327,6 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {   // src_
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
 
-// 1 / sqrt(d): v_rsq_f64 and two Newton steps
-__device__ __forceinline__ double dense_rsqrt(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  r = r * fma(-0.5 * d * r, r, 1.5);
-  r = r * fma(-0.5 * d * r, r, 1.5);
-  return r;
-}
-
 // wave 0: Cholesky factor of the diagonal block at k0, lane = row, the row in registers.  Column j of the
 // factor goes to LDS as soon as it exists (Lt[j][r] = L[r][j]) and is read back as wave-uniform operands
 // for the rank-1 update (LDS operations of one wave execute in order: no barrier).  Lr = 1 / diagonal.
@@ -351,7 +343,7 @@ __device__ __forceinline__ bool chol_diag_wave(const double* __restrict__ S, int
   for (int j = 0; j < kNB; ++j) {
     double d = lane_bcast(a[j], j);
     if (!(d > 0.0)) { bad = true; d = 1.0; }
-    const double rd = dense_rsqrt(d);
+    const double rd = mf_rsqrt(d);
     const double l = (lane >= j) ? a[j] * rd : 0.0;
     Lt[j * kLs + lane] = l;
     if (lane == 0) Lr[j] = rd;

@@ -253,19 +253,36 @@ __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, co
 
 // 3x3 SPD inverse through Cholesky (Eigen llt().solve(I) in Ceres). a = {a00,a10,a11,a20,a21,a22}.
 // Returns false if not positive definite.
+// 1/x and 1/sqrt(x) to within an ulp or two: v_rcp_f64 / v_rsq_f64 and two Newton steps.  The correctly rounded
+// division and square root cost about thirty instructions each on CDNA, and every wavelet pass of K2 / K4 executes
+// them whether or not a lane needs the result.
+__device__ __forceinline__ double mf_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ double mf_rsqrt(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * fma(-0.5 * d * r, r, 1.5);
+  r = r * fma(-0.5 * d * r, r, 1.5);
+  return r;
+}
+
+// inverse of a 3x3 SPD matrix through its Cholesky factor; the pivots' reciprocal square roots are all it needs
 __device__ __forceinline__ bool spd3_inverse(const double* a, double* ci /*c00,c10,c11,c20,c21,c22*/) {
   const double d0 = a[0];
   if (!(d0 > 0.0)) return false;
-  const double l00 = sqrt(d0);
-  const double l10 = a[1] / l00, l20 = a[3] / l00;
+  const double i00 = mf_rsqrt(d0);
+  const double l10 = a[1] * i00, l20 = a[3] * i00;
   const double d1 = a[2] - l10 * l10;
   if (!(d1 > 0.0)) return false;
-  const double l11 = sqrt(d1);
-  const double l21 = (a[4] - l20 * l10) / l11;
+  const double i11 = mf_rsqrt(d1);
+  const double l21 = (a[4] - l20 * l10) * i11;
   const double d2 = a[5] - l20 * l20 - l21 * l21;
   if (!(d2 > 0.0)) return false;
-  const double l22 = sqrt(d2);
-  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i22 = mf_rsqrt(d2);
   const double i10 = -l10 * i00 * i11;
   const double i21 = -l21 * i11 * i22;
   const double i20 = -(l20 * i00 + l21 * i10) * i22;

@@ -64,16 +64,6 @@ struct MfGeo {
   double px, py, n, d, f;
 };
 
-// 1/x to within an ulp or two: v_rcp_f64 and two Newton steps (the correctly rounded division costs twice as
-// much and the operator only has to be consistent to rounding error)
-__device__ __forceinline__ double mf_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
-}
-
 // cd: camera slot data (LDS or registers), X: point.  SMALL = false: no camera of the tile is in the
 // small-angle branch, Ep is E.
 template <bool SMALL = true>
@@ -376,7 +366,7 @@ __device__ __forceinline__ void mf_blocks(const double* cd, double x0, double x1
   const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
   const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
   const double f = cd[12], k1 = cd[13], k2 = cd[14];
-  const double iz = 1.0 / P2;
+  const double iz = mf_rcp(P2);
   const double px = -P0 * iz, py = -P1 * iz;
   const double n = px * px + py * py;
   const double d = 1.0 + n * (k1 + k2 * n);
@@ -466,7 +456,7 @@ __device__ __forceinline__ void mf_resid_E(const double* cd, double x0, double x
   const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
   const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
   const double f = cd[12], k1 = cd[13], k2 = cd[14];
-  const double iz = 1.0 / P2;
+  const double iz = mf_rcp(P2);
   const double px = -P0 * iz, py = -P1 * iz;
   const double n = px * px + py * py;
   const double d = 1.0 + n * (k1 + k2 * n);
@@ -807,7 +797,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         const double m1 = u1 + geo.E[3] * z0 + geo.E[4] * z1 + geo.E[5] * z2;
         mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
         if (pos == 0) {
-          yp[3 * p] = z0 / sp[3 * p]; yp[3 * p + 1] = z1 / sp[3 * p + 1]; yp[3 * p + 2] = z2 / sp[3 * p + 2];
+          yp[3 * p] = z0 * mf_rcp(sp[3 * p]); yp[3 * p + 1] = z1 * mf_rcp(sp[3 * p + 1]); yp[3 * p + 2] = z2 * mf_rcp(sp[3 * p + 2]);
           const double c0 = rec[0] - z0, c1 = rec[1] - z1, c2 = rec[2] - z2;
           Xc[3 * p] = c0; Xc[3 * p + 1] = c1; Xc[3 * p + 2] = c2;
           const double e0 = rec[0] - c0, e1 = rec[1] - c1, e2 = rec[2] - c2;   // step norm exactly as Ceres: |x - x_cand|
@@ -842,7 +832,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
       const double z1 = rec[4] - (rec[7] * a0 + rec[8] * a1 + rec[10] * a2);
       const double z2 = rec[5] - (rec[9] * a0 + rec[10] * a1 + rec[11] * a2);
       if (tid == 0) {
-        yp[3 * p] = z0 / sp[3 * p]; yp[3 * p + 1] = z1 / sp[3 * p + 1]; yp[3 * p + 2] = z2 / sp[3 * p + 2];
+        yp[3 * p] = z0 * mf_rcp(sp[3 * p]); yp[3 * p + 1] = z1 * mf_rcp(sp[3 * p + 1]); yp[3 * p + 2] = z2 * mf_rcp(sp[3 * p + 2]);
         const double c0 = rec[0] - z0, c1 = rec[1] - z1, c2 = rec[2] - z2;
         Xc[3 * p] = c0; Xc[3 * p + 1] = c1; Xc[3 * p + 2] = c2;
         const double e0 = rec[0] - c0, e1 = rec[1] - c1, e2 = rec[2] - c2;
@@ -920,7 +910,7 @@ __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __rest
       const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
       const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
       const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
-      const double iz = 1.0 / P2;
+      const double iz = mf_rcp(P2);
       const double px = -P0 * iz, py = -P1 * iz;
       const double n = px * px + py * py;
       const double d = 1.0 + n * (cd[13] + cd[14] * n);
@@ -940,7 +930,7 @@ __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __rest
         const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
         const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
         const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
-        const double iz = 1.0 / P2;
+        const double iz = mf_rcp(P2);
         const double px = -P0 * iz, py = -P1 * iz;
         const double n = px * px + py * py;
         const double d = 1.0 + n * (cd[13] + cd[14] * n);
