@@ -58,7 +58,7 @@ def test_ranks_agree_with_single_rank(single, world, tmp_path):
 def test_ranks_agree_with_single_rank_empty_shards(single, tmp_path):
     """Eight ranks for a problem of seven default-size tiles: at least one rank owns nothing and still has to take
     part in every reduction with zeros."""
-    ranks = launch(8, tmp_path)
+    ranks = launch(8, tmp_path, "medium", {"MIBA_TILE_CHUNKS": "8"})
     assert any(np.abs(o["y_pt"]).sum() == 0.0 for o in ranks)
     check(ranks, single, 8)
 

@@ -8,8 +8,8 @@ run MIBA_TILE_CHUNKS=16 || exit 1
 run MIBA_POINT_ORDER=0 || exit 1
 run MIBA_FORCE_RCCL=1 || exit 1
 run MIBA_DENSE_PLAN=0 || exit 1
-# the exact solve and SCHUR_JACOBI need the two-pass matrix-free kernels: their tests are skipped for these three
-EXTRA="--deselect tests/test_gpu_dense.py"
+# the exact solve and SCHUR_JACOBI need the two-pass matrix-free kernels: the tests that use them are skipped for these three
+EXTRA="--deselect tests/test_gpu_dense.py --deselect tests/test_gpu_multirank.py"
 run MIBA_K2_ONEPASS=1 || exit 1
 run MIBA_MF=0 || exit 1
 run MIBA_DENSE=0 || exit 1
