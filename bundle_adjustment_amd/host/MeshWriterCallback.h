@@ -1,5 +1,7 @@
-// Per-iteration PLY dump, as /root/reference/src/MeshWriterCallback.h:11-28.  Disabled when the
-// environment variable BA_ITERATION_PLY is "0" (a Final-13682 dump is ~150 MB of text per iteration).
+// Iteration callback that dumps the current state as mesh_<prefix>_<iteration>.ply, the job of the reference's
+// callback of the same name (/root/reference/src/MeshWriterCallback.h:11-28).  Here the dump is a snapshot handed
+// to BundleAdjustment's background writer, so the Levenberg-Marquardt loop does not wait for the file; the
+// environment variable BA_ITERATION_PLY=0 switches the dumps off (a Final-13682 dump is ~150 MB of text).
 #pragma once
 
 #include <cstdio>
@@ -12,23 +14,20 @@
 
 class MeshWriterCallback : public ceres::IterationCallback {
 public:
-    explicit MeshWriterCallback(BundleAdjustment* ba, std::string prefix):ba(ba), prefix(prefix){
-        const char* e = getenv("BA_ITERATION_PLY");
-        enabled = !(e && e[0] == '0');
+    explicit MeshWriterCallback(BundleAdjustment* owner, std::string file_prefix) : ba(owner), prefix(std::move(file_prefix)) {
+        const char* knob = getenv("BA_ITERATION_PLY");
+        enabled = !(knob && knob[0] == '0');
     }
 
-    ~MeshWriterCallback() {}
-
-    // false: BA_ITERATION_PLY=0, the callback would do nothing (solve() then leaves it out, so that no state is
-    // copied back per iteration on its account)
+    // false: the callback would do nothing; solve() then leaves it out of options.callbacks, so that no state is copied
+    // back from the device per iteration on its account
     bool isEnabled() const { return enabled; }
 
-    ceres::CallbackReturnType operator()(const ceres::IterationSummary &summary) {
-        if(enabled && summary.iteration % 1 == 0) {
-            char name[256];
-            snprintf(name, sizeof(name), "mesh_%s_%d.ply", prefix.c_str(), summary.iteration);
-            ba->WriteToPLYFileAsync(name);   // snapshot now, text later: the LM loop does not wait for the file
-        }
+    ceres::CallbackReturnType operator()(const ceres::IterationSummary& summary) {
+        if (!enabled) return ceres::SOLVER_CONTINUE;
+        char name[256];
+        snprintf(name, sizeof(name), "mesh_%s_%d.ply", prefix.c_str(), summary.iteration);
+        ba->WriteToPLYFileAsync(name);
         return ceres::SOLVER_CONTINUE;
     }
 

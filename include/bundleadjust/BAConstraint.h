@@ -1,30 +1,35 @@
-// Reprojection constraint, same surface as /root/reference/include/bundleadjust/BAConstraint.h:17-32.
-// The functor evaluates the 9-parameter BAL camera (BASELINE.json north_star; the reference's own
-// BAL form at src/BAConstraint.cpp:89-128) on the host for ONE observation; the solve path never
-// allocates one of these per observation, it runs the same model in HIP (libmiba K1).
+// One reprojection constraint on the host.
+//
+// Public surface of the reference's class (/root/reference/include/bundleadjust/BAConstraint.h:17-32): constructor,
+// templated functor, printOp, create.  What is behind it differs: the functor evaluates the 9-parameter BAL camera
+// (BASELINE.json north_star; the reference keeps that form commented at src/BAConstraint.cpp:89-128), and the solve
+// path never builds one of these per observation — libmiba runs the same model in HIP.  The class stays for
+// callers that want the residual or its automatic derivative of a single observation (tests do).
 #pragma once
 
-#include <ceres/cost_function.h>
 #include <ceres/ceres.h>
+#include <ceres/cost_function.h>
 #include <opencv2/opencv.hpp>
-#include "bundleadjust/Dataloader.h"
 
+#include "bundleadjust/Dataloader.h"
 #include "BalDataloader.h"
 
 class BAConstraint {
-
 public:
+    // observation = (x, y, unused); estimatedPose = column-major 4x4 (kept, the BAL model does not use it)
     BAConstraint(const Eigen::Vector3f& observation, const float * estimatedPose);
 
-    // blocks: point[3], rot[3] (angle-axis), tr[3], intrinsics[6] = fx,fy,ox,oy,k1,k2; residuals[2]
+    // the ceres::AutoDiffCostFunction<BAConstraint, 2, 3, 3, 3, 6> the reference builds for every observation
+    static ceres::CostFunction* create(const Eigen::Vector3f& observation, const float * estimatedPose);
+
+    // parameter blocks: point[3] | rot[3] angle-axis | tr[3] | intrinsics[6] = fx fy ox oy k1 k2; residuals[2] = predicted - observed
     template <typename T>
     bool operator()(const T* const point, const T* const rot, const T* const tr, const T* const intrinsics, T* residuals) const;
 
+    // prints the intermediate quantities of one evaluation (debugging aid of the reference)
     bool printOp(double * point, double * rot, double * tr, double * intrinsics, const float * estimatedPose) const;
 
-    static ceres::CostFunction* create(const Eigen::Vector3f& observation, const float * estimatedPose);
-
 protected:
-    Eigen::Matrix4f pose;
     const Eigen::Vector3f observation;
+    Eigen::Matrix4f pose;
 };
