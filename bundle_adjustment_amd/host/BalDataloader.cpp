@@ -310,9 +310,10 @@ BalDataloader::BalDataloader(std::string path) {
 BalDataloader::~BalDataloader() {}
 
 std::vector<cv::Point2f> BalDataloader::getObservations() const {
-    std::vector<cv::Point2f> obs;
-    obs.reserve(observations.size());
-    for (auto &pt : observations) obs.emplace_back(pt.first, pt.second);
+    // same bytes: two floats per observation in both element types
+    static_assert(sizeof(cv::Point2f) == 2 * sizeof(float) && sizeof(std::pair<float, float>) == 2 * sizeof(float), "layout");
+    std::vector<cv::Point2f> obs(observations.size());
+    if (!obs.empty()) memcpy(static_cast<void *>(obs.data()), static_cast<const void *>(observations.data()), obs.size() * sizeof(cv::Point2f));
     return obs;
 }
 

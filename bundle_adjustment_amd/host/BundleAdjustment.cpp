@@ -122,12 +122,28 @@ void BundleAdjustment::createProblem() {
     std::vector<int32_t> obs_cam(n_obs), obs_pt(n_obs);
     std::vector<double> obs_xy(2 * (size_t) n_obs);
     int invalidObs = 0;
-    for (int i = 0; i < n_obs; ++i) {
-        obs_cam[i] = dataset->getObsCam(i);
-        obs_pt[i] = dataset->getObsPoint(i);
-        if (obs_pt[i] == -1) invalidObs++; // no 3d point to 2d point
-        obs_xy[2 * (size_t) i] = observations[i].x;      // float -> double, as observation.cast<T>()
-        obs_xy[2 * (size_t) i + 1] = observations[i].y;
+    {
+        // ranges of observations converted by worker threads (the accessors are const and the ranges disjoint)
+        unsigned n_thr = std::thread::hardware_concurrency();
+        if (n_thr < 1) n_thr = 1;
+        if (n_thr > 16) n_thr = 16;
+        if (n_obs < (1 << 18)) n_thr = 1;
+        std::vector<int> invalid(n_thr, 0);
+        auto convert = [&](unsigned t) {
+            const long long a = (long long) n_obs * t / n_thr, b = (long long) n_obs * (t + 1) / n_thr;
+            for (long long i = a; i < b; ++i) {
+                obs_cam[i] = dataset->getObsCam((int) i);
+                obs_pt[i] = dataset->getObsPoint((int) i);
+                if (obs_pt[i] == -1) invalid[t]++; // no 3d point to 2d point
+                obs_xy[2 * (size_t) i] = observations[i].x;      // float -> double, as observation.cast<T>()
+                obs_xy[2 * (size_t) i + 1] = observations[i].y;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(convert, t);
+        convert(0);
+        for (auto &x : th) x.join();
+        for (int v : invalid) invalidObs += v;
     }
 
     if (!problem) {
