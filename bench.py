@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--preconditioner", choices=["jacobi", "schur_jacobi"], default="jacobi",
                     help="PCG preconditioner; jacobi is Ceres' default and what the reference runs with")
+    ap.add_argument("--loss", default="none", help="none (what the reference runs with), huber:<a> or cauchy:<a>: robust loss on every "
+                    "residual block (SURVEY 8f rank 4); not the headline configuration")
     ap.add_argument("--ttt", type=int, default=80, help="also report time-to-cost-tolerance over at most this many LM iterations")
     args = ap.parse_args()
 
@@ -48,6 +50,10 @@ def main():
     import torch
     from bundle_adjustment_amd import miba, synth
     precond = miba.PRECOND_SCHUR_JACOBI if args.preconditioner == "schur_jacobi" else miba.PRECOND_JACOBI
+    loss_kw = {}
+    if args.loss != "none":
+        kind, _, a = args.loss.partition(":")
+        loss_kw = dict(loss_type={"huber": miba.LOSS_HUBER, "cauchy": miba.LOSS_CAUCHY}[kind], loss_scale=float(a or 1.0))
 
     # RCCL prints a version banner on C stdout when the first communicator is made.  The contract is ONE JSON line on
     # stdout, so file descriptor 1 points at stderr until the line is printed.
@@ -115,7 +121,7 @@ def main():
         n_this = warm_left + steps_left
         opt = miba.default_options(max_num_iterations=n_this, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
                                    function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
-                                   pcg_check_every=args.check_every, preconditioner_type=precond)
+                                   pcg_check_every=args.check_every, preconditioner_type=precond, **loss_kw)
         marks = {}
 
         def cb(it, warm=warm_left, n=n_this):
@@ -233,9 +239,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "synthetic BAL-format stand-in for %s: %d cameras / %d points / %d observations, seed %d, "
                                "initial state = ground truth + N(0,%g) on camera rot/trans + N(0,%g) on points; "
-                               "LM + ITERATIVE_SCHUR (implicit Schur, %s preconditioner, eta=%g); %s kernels"
+                               "LM + ITERATIVE_SCHUR (implicit Schur, %s preconditioner, eta=%g); %s kernels%s"
                                % (args.config, n_cam, n_pt, n_obs, seed, args.sigma_cam, args.sigma_x, args.preconditioner.upper(), args.eta,
-                                  "matrix-free" if mf else "stored-Jacobian"),
+                                  "matrix-free" if mf else "stored-Jacobian", "" if args.loss == "none" else "; loss " + args.loss),
                    "pcg_iterations_in_timed_steps": n_cg,
                    "successful_steps_in_timed_steps": sum(r["step_is_successful"] for r in timed),
                    "cost_first": its[0]["cost"], "cost_last": summ["final_cost"],
@@ -269,7 +275,7 @@ def main():
         # iteration at this size), reported is the solver time at the first iteration whose cost is <= (1 + 1e-6) C*.
         solver.set_state(cams0, pts0)
         o2 = miba.default_options(max_num_iterations=args.ttt, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
-                                  pcg_check_every=args.check_every, preconditioner_type=precond)
+                                  pcg_check_every=args.check_every, preconditioner_type=precond, **loss_kw)
         its2, summ2 = solver.solve(o2)
         cstar = summ2["final_cost"]
         hit = next(r for r in its2 if r["cost"] <= (1.0 + 1e-6) * cstar)
@@ -288,7 +294,7 @@ def main():
             solver.set_state(c1, p1)
             o3 = miba.default_options(max_num_iterations=20, linear_solver_type=miba.ITERATIVE_SCHUR, eta=args.eta,
                                       function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
-                                      pcg_check_every=args.check_every, preconditioner_type=precond)
+                                      pcg_check_every=args.check_every, preconditioner_type=precond, **loss_kw)
             sync()
             its3, summ3 = solver.solve(o3)
             sync()
@@ -307,7 +313,7 @@ def main():
         cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
         oo = O.default_options(max_num_iterations=args.cpu_iters, linear_solver=O.ITERATIVE_SCHUR, eta=args.eta,
                                function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0, num_threads=cores,
-                               preconditioner=O.SCHUR_JACOBI if args.preconditioner == "schur_jacobi" else O.JACOBI)
+                               preconditioner=O.SCHUR_JACOBI if args.preconditioner == "schur_jacobi" else O.JACOBI, **loss_kw)
         _, _, oits, osumm = O.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], oo)
         # compare on the iterations both runs have (the first miba_solve call starts from the same state)
         n_cpu = min(len(oits), len(first_its)) - 1

@@ -118,6 +118,8 @@ struct miba_handle_s {
   int32_t n_giant = 0;
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
+  Loss loss = {kLossNone, 1.0};                   // robust loss of the current solve (options.loss_type / loss_scale)
+  double* d_omega = nullptr;                      // [n_slots] loss weights rho' of the current linearisation (loss only)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
   double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
   double *d_slab64 = nullptr, *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
@@ -316,8 +318,12 @@ int eval_cost(miba_handle h, const double* cam, const double* X, bool reduce = t
   if (rc) return rc;
   if (h->n_tiles && h->use_mf) {
     Timed t(h, MIBA_K_EVAL_COST);
-    hipLaunchKernelGGL(k_mf_cost, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles,
-                       h->d_giant, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct_cand, X, h->d_part_tile);
+#define MIBA_COST_ARGS                                                                                                   \
+  dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant, h->d_grps,   \
+      h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct_cand, X, h->d_part_tile, h->loss
+    if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_cost<true>, MIBA_COST_ARGS);
+    else hipLaunchKernelGGL(k_mf_cost<false>, MIBA_COST_ARGS);
+#undef MIBA_COST_ARGS
   } else if (h->n_tiles) {
     Timed t(h, MIBA_K_EVAL_COST);
     hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
@@ -340,21 +346,30 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want
 #define MIBA_INIT_ARGS(list)                                                                                              \
   h->d_tiles, list, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm,   \
       h->d_X, h->d_sp, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_gp, want_diag ? h->d_dgp : (double*)nullptr,    \
-      h->d_ptrec, h->d_slab64, h->d_part_tile, h->d_ctl
-    if (h->k2_onepass) {
-      hipLaunchKernelGGL((k_mf_init<false, true>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
+      h->d_ptrec, h->d_slab64, h->d_part_tile, h->d_ctl, h->loss, h->d_omega
+    if (h->loss.type != kLossNone) {
+      // robust loss (set_loss has checked that the two-pass kernels are in use): the point side leaves rho' per slot
+      hipLaunchKernelGGL((k_mf_init<false, false, true>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
                          MIBA_INIT_ARGS((const int32_t*)nullptr));
       if (h->n_giant)
-        hipLaunchKernelGGL((k_mf_init<true, true>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
+        hipLaunchKernelGGL((k_mf_init<true, false, true>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
+      if (h->n_seg)
+        hipLaunchKernelGGL(k_mf_camrows<true>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                           h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+    } else if (h->k2_onepass) {
+      hipLaunchKernelGGL((k_mf_init<false, true, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
+                         MIBA_INIT_ARGS((const int32_t*)nullptr));
+      if (h->n_giant)
+        hipLaunchKernelGGL((k_mf_init<true, true, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
     } else {
       // point side (wavelets), then camera side over the camera-major copy of the observations
-      hipLaunchKernelGGL((k_mf_init<false, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
+      hipLaunchKernelGGL((k_mf_init<false, false, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
                          MIBA_INIT_ARGS((const int32_t*)nullptr));
       if (h->n_giant)
-        hipLaunchKernelGGL((k_mf_init<true, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
+        hipLaunchKernelGGL((k_mf_init<true, false, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
       if (h->n_seg)
-        hipLaunchKernelGGL(k_mf_camrows, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
-                           h->d_ct, h->d_cm, h->d_ptrec, h->d_slabB);
+        hipLaunchKernelGGL(k_mf_camrows<false>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                           h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
     }
 #undef MIBA_INIT_ARGS
   }
@@ -372,6 +387,27 @@ int cam_reduce64(miba_handle h, const double* sc) {
   hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam,
                      segs ? h->d_cam_seg_off : h->d_cam_row_off, segs ? h->d_slabB : h->d_slab64, sc, h->d_camacc);
   HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
+// robust loss of this solve: validated, kept in the handle for the kernel launches; the weight array is allocated on
+// first use.  The loss lives in the two-pass matrix-free kernels only.
+int set_loss(miba_handle h, const miba_options* o) {
+  if (o->loss_type == MIBA_LOSS_NONE) {
+    h->loss = Loss{kLossNone, 1.0};
+    return MIBA_OK;
+  }
+  if (o->loss_type != MIBA_LOSS_HUBER && o->loss_type != MIBA_LOSS_CAUCHY) return fail(h, MIBA_ERR_INVALID, "unknown loss_type %d", (int)o->loss_type);
+  if (!(o->loss_scale > 0.0) || !std::isfinite(o->loss_scale)) return fail(h, MIBA_ERR_INVALID, "loss_scale must be positive and finite");
+  if (!h->use_mf || h->k2_onepass)
+    return fail(h, MIBA_ERR_INVALID, "a loss function needs the two-pass matrix-free kernels (MIBA_MF=0 or MIBA_K2_ONEPASS=1 is set)");
+  if (o->preconditioner_type == MIBA_PRECOND_SCHUR_JACOBI && o->linear_solver_type == MIBA_ITERATIVE_SCHUR)
+    return fail(h, MIBA_ERR_INVALID, "preconditioner SCHUR_JACOBI is not available together with a loss function");
+  if (!h->d_omega) {
+    int rc = dev_alloc(h, &h->d_omega, h->n_slots ? h->n_slots : 1);
+    if (rc) return rc;
+  }
+  h->loss = Loss{o->loss_type == MIBA_LOSS_HUBER ? kLossHuber : kLossCauchy, o->loss_scale};
   return MIBA_OK;
 }
 
@@ -447,9 +483,13 @@ int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* pa
   if (h->use_mf) {
     if (h->n_tiles) {
       Timed t(h, MIBA_K_SCHUR_MATVEC);
-      hipLaunchKernelGGL(k_mf_matvec, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles,
-                         h->d_giant, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm,
-                         h->d_sc, h->d_X, h->d_ptrec, x, h->d_slab9, ctl);
+#define MIBA_MATVEC_ARGS                                                                                                \
+  dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant, h->d_grps,  \
+      h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec,        \
+      (const double*)h->d_omega, x, h->d_slab9, ctl
+      if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_matvec<true>, MIBA_MATVEC_ARGS);
+      else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
+#undef MIBA_MATVEC_ARGS
     }
     hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
                        h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, part_xy, ctl);
@@ -586,6 +626,7 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
 // N = 9 n_cam (rounded up to 64) <= kDenseMaxN; MIBA_DENSE=0 keeps the PCG-to-eta_exact stand-in.
 bool dense_wanted(miba_handle h, const miba_options* o) {
   if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR || !h->use_mf) return false;
+  if (o->loss_type != MIBA_LOSS_NONE) return false;   // the dense assembly kernels carry no loss weights: PCG to eta_exact
   const char* e = getenv("MIBA_DENSE");
   if (e && atoi(e) == 0) return false;
   const size_t N = (9 * (size_t)h->n_cam + kNB - 1) / kNB * kNB;
@@ -740,13 +781,17 @@ int backsub_and_candidate(miba_handle h, bool reduce = true) {
   if (h->use_mf) {
     if (h->n_tiles) {
       Timed t(h, MIBA_K_BACKSUB);
-      hipLaunchKernelGGL(k_mf_backsub<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, (const int32_t*)nullptr,
-                         h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct, h->d_cm, h->d_sc, h->d_sp,
-                         h->d_ptrec, h->d_px, h->d_yp, h->d_Xc, h->d_part_tile);
-      if (h->n_giant)
-        hipLaunchKernelGGL(k_mf_backsub<true>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
-                           h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct, h->d_cm, h->d_sc, h->d_sp, h->d_ptrec,
-                           h->d_px, h->d_yp, h->d_Xc, h->d_part_tile);
+#define MIBA_BACKSUB_ARGS(n_blocks, list)                                                                                 \
+  dim3((unsigned)(n_blocks)), dim3(kChunk), 0, h->st, h->d_tiles, list, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, \
+      h->d_oxy, h->d_ct, h->d_cm, h->d_sc, h->d_sp, h->d_ptrec, h->d_px, h->d_yp, h->d_Xc, h->d_part_tile, (const double*)h->d_omega
+      if (h->loss.type != kLossNone) {
+        hipLaunchKernelGGL((k_mf_backsub<false, true>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));
+        if (h->n_giant) hipLaunchKernelGGL((k_mf_backsub<true, true>), MIBA_BACKSUB_ARGS(h->n_giant, h->d_giant));
+      } else {
+        hipLaunchKernelGGL((k_mf_backsub<false, false>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));
+        if (h->n_giant) hipLaunchKernelGGL((k_mf_backsub<true, false>), MIBA_BACKSUB_ARGS(h->n_giant, h->d_giant));
+      }
+#undef MIBA_BACKSUB_ARGS
     }
   } else if (h->n_tiles) {
     Timed t(h, MIBA_K_BACKSUB);
@@ -873,6 +918,9 @@ void miba_default_options(miba_options* o) {
   o->eta = 1e-1;
   o->eta_exact = 1e-12;
   o->max_solver_time_in_seconds = 1e9;
+  o->loss_type = MIBA_LOSS_NONE;
+  o->reserved = 0;
+  o->loss_scale = 1.0;
 }
 
 const char* miba_last_error(miba_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
@@ -1174,6 +1222,7 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   h->d_S = nullptr; h->d_Linv = nullptr; h->d_dflag = nullptr; h->dense_N = 0;
   h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false; h->d_camacc2 = nullptr;
+  h->d_omega = nullptr;
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
   // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
   ALLOC(h->d_slab64, (!h->use_mf || h->k2_onepass) ? (size_t)kK2W * n_rows : (size_t)1); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
@@ -1383,7 +1432,9 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
   HIPCHK(h, hipSetDevice(h->device));
   h->scale_valid = false;
   h->jac_valid = false;
-  int rc = ensure_jacobian(h, opt);
+  int rc = set_loss(h, opt);
+  if (rc) return rc;
+  rc = ensure_jacobian(h, opt);
   if (rc) return rc;
   rc = schur_init(h, radius, opt);
   if (rc) return rc;
@@ -1517,7 +1568,8 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
   S.num_active_points = (int32_t)h->plan.pt_orig.size();
   S.exact_linear_solver = dense_wanted(h, &o) ? 1 : 0;
   snprintf(S.message, sizeof(S.message), "Maximum number of iterations reached.");
-  int rc;
+  int rc = set_loss(h, &o);
+  if (rc) return rc;
 
   // best-state buffers: d_cam_cand / d_Xc double as candidates, so keep the best state on the host side of
   // the swap: x (d_cam, d_X) is always the last ACCEPTED state, which in the monotonic algorithm is also

@@ -14,6 +14,8 @@
 // E_s y = E (sp.y).
 #pragma once
 
+#include <cfloat>
+
 #include "miba_kernels.hpp"
 
 namespace miba {
@@ -56,6 +58,30 @@ __device__ __forceinline__ void mf_stage_cam(double* dst, int cam, const double*
     dst[18 + i] = small ? xs[3 + i] : (T[i] * xs[3] + T[3 + i] * xs[4] + T[6 + i] * xs[5]);  // N' x_t
   dst[21] = xs[6]; dst[22] = xs[7]; dst[23] = xs[8];
   dst[24] = small ? 1.0 : 0.0;
+}
+
+// Robust loss on every residual block (ceres::LossFunction; the reference passes nullptr, src/BundleAdjustment.cpp:69).
+// HuberLoss(a) and CauchyLoss(a) as Ceres evaluates them on s = |r|^2: rho(s) and rho'(s).  Both have rho'' <= 0, for
+// which Ceres' Corrector multiplies the block's residual and Jacobian rows by sqrt(rho') and nothing else: in J'J, J'r
+// and the model cost change every observation's terms carry the weight om = rho', the cost is 1/2 sum rho.
+// The point-side pass of K2 leaves om per slot for K3 and K4; kernels are templated on LOSS, so the default
+// (no loss, what the reference runs) executes the same code as before.
+enum { kLossNone = 0, kLossHuber = 1, kLossCauchy = 2 };
+struct Loss { int type; double a; };
+__device__ __forceinline__ void mf_loss(const Loss L, double s, double& rho, double& om) {
+  const double b = L.a * L.a;
+  if (L.type == kLossHuber && s > b) {
+    const double r = sqrt(s);
+    rho = 2.0 * L.a * r - b;
+    om = fmax(DBL_MIN, L.a / r);
+  } else if (L.type == kLossCauchy) {
+    const double sum = 1.0 + s / b;
+    rho = b * log(sum);
+    om = fmax(DBL_MIN, 1.0 / sum);
+  } else {
+    rho = s;
+    om = 1.0;
+  }
 }
 
 struct MfGeo {
@@ -177,9 +203,10 @@ __device__ __forceinline__ void mf_load_rec9(double* rec, const double* __restri
 
 // Wavelet loop of one wave over its tile (wavelets wv, wv+4, ...), software-pipelined: the index word of
 // wavelet i+2 and the point records of wavelet i+1 are in flight while wavelet i is computed.
-template <bool SMALL>
+template <bool SMALL, bool LOSS>
 __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __restrict__ idx, const int2* __restrict__ wl,
-                                               const double* __restrict__ ptrec, const double* s_cam, double* s_acc) {
+                                               const double* __restrict__ ptrec, const double* __restrict__ omega,
+                                               const double* s_cam, double* s_acc) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nwl = t.nslot / kWave;
   const int acc_stride = t.ncs * 9;
@@ -196,8 +223,9 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
   int32_t w_nxt = idxp[(size_t)q1 * kWave];
   int2 m_nxt = wlp[q1];
   // one wavelet: index word w, point record rec (of the lane's point), longest point run maxrun
-  auto wavelet = [&](const double* rec, const int32_t w, const int maxrun) {
+  auto wavelet = [&](const double* rec, const int32_t w, const int maxrun, const int qw) {
     const bool valid = w >= 0;
+    const double om = (LOSS && valid) ? omega[(size_t)t.slot0 + (size_t)qw * kWave + lane] : 1.0;   // loss weight rho'
     const int cs = valid ? ((w >> 8) & 0xFF) : 0, pl = w & 0xFF;
     const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
     MfGeo geo;
@@ -209,6 +237,7 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
     double v0 = valid ? geo.E[0] * u0 + geo.E[3] * u1 : 0.0;
     double v1 = valid ? geo.E[1] * u0 + geo.E[4] * u1 : 0.0;
     double v2 = valid ? geo.E[2] * u0 + geo.E[5] * u1 : 0.0;
+    if (LOSS) { v0 *= om; v1 *= om; v2 *= om; }
     mf_seg_scan3(v0, v1, v2, lane, pos, maxrun);
     // total of the run sits in its last lane
     const int last = (lane - pos + cnt - 1) << 2;
@@ -218,8 +247,9 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
       const double y0 = -(rec[3] * a0 + rec[4] * a1 + rec[6] * a2);
       const double y1 = -(rec[4] * a0 + rec[5] * a1 + rec[7] * a2);
       const double y2 = -(rec[6] * a0 + rec[7] * a1 + rec[8] * a2);
-      const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
-      const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
+      double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
+      double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
+      if (LOSS) { w0 *= om; w1 *= om; }
       double o[9];
       mf_transpose(geo, rec[0], rec[1], rec[2], w0, w1, o);
       // consecutive points go to different accumulator copies: lanes of one ds_add rarely share an address
@@ -238,7 +268,7 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
       const int q2 = min(q + 8, q_last);
       const int32_t w_n2 = idxp[(size_t)q2 * kWave];
       const int2 m_n2 = wlp[q2];
-      wavelet(rec_a, w_cur, m_cur.y);
+      wavelet(rec_a, w_cur, m_cur.y, q);
       w_cur = w_nxt; m_cur = m_nxt; w_nxt = w_n2; m_nxt = m_n2;
     }
     q += 4;
@@ -248,7 +278,7 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
       const int q2 = min(q + 8, q_last);
       const int32_t w_n2 = idxp[(size_t)q2 * kWave];
       const int2 m_n2 = wlp[q2];
-      wavelet(rec_b, w_cur, m_cur.y);
+      wavelet(rec_b, w_cur, m_cur.y, q);
       w_cur = w_nxt; m_cur = m_nxt; w_nxt = w_n2; m_nxt = m_n2;
     }
     q += 4;
@@ -256,7 +286,7 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
   }
 }
 
-template <bool GIANT>
+template <bool GIANT, bool LOSS>
 __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, double* s_acc, double* s4,
                                                    const Tile* __restrict__ tiles,
                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
@@ -265,6 +295,7 @@ __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, d
                                                    const double* __restrict__ ct, const double* __restrict__ cm,
                                                    const double* __restrict__ sc, const double* __restrict__ X,
                                                    const double* __restrict__ ptrec /*[npt][kPtRec]*/,
+                                                   const double* __restrict__ omega /*[slot] loss weights, LOSS only*/,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/) {
   const Tile t = tiles[tile_index];
   if (!GIANT && t.giant) return;
@@ -277,8 +308,8 @@ __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, d
     }
     for (int i = tid; i < kAccCopies * t.ncs * 9; i += kChunk) s_acc[i] = 0.0;
     const int any_small = __syncthreads_or(small);
-    if (any_small) mf_matvec_tile<true>(t, idx, wl, ptrec, s_cam, s_acc);
-    else mf_matvec_tile<false>(t, idx, wl, ptrec, s_cam, s_acc);
+    if (any_small) mf_matvec_tile<true, LOSS>(t, idx, wl, ptrec, omega, s_cam, s_acc);
+    else mf_matvec_tile<false, LOSS>(t, idx, wl, ptrec, omega, s_cam, s_acc);
     __syncthreads();  // every wave's LDS atomics have landed
     const int acc_stride = t.ncs * 9;
     for (int i = tid; i < acc_stride; i += kChunk) {
@@ -305,6 +336,7 @@ __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, d
           mf_geom(cd, x0, x1, x2, geo);
           mf_forward(geo, cd, x0, x1, x2, u0, u1);
           v0 = geo.E[0] * u0 + geo.E[3] * u1; v1 = geo.E[1] * u0 + geo.E[4] * u1; v2 = geo.E[2] * u0 + geo.E[5] * u1;
+          if (LOSS) { const double om = omega[slot]; v0 *= om; v1 *= om; v2 *= om; }
         }
         a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
       }
@@ -321,8 +353,9 @@ __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, d
         double u0, u1;
         mf_geom(cd, x0, x1, x2, geo);
         mf_forward(geo, cd, x0, x1, x2, u0, u1);
-        const double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
-        const double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
+        double w0 = u0 + geo.E[0] * y0 + geo.E[1] * y1 + geo.E[2] * y2;
+        double w1 = u1 + geo.E[3] * y0 + geo.E[4] * y1 + geo.E[5] * y2;
+        if (LOSS) { const double om = omega[slot]; w0 *= om; w1 *= om; }
         double o[9];
         mf_transpose(geo, x0, x1, x2, w0, w1, o);
         double* dst = slab + 9 * (size_t)slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
@@ -336,6 +369,7 @@ __device__ __forceinline__ void mf_matvec_block(int tile_index, double* s_cam, d
 // K3-mf launch: the first n_giant blocks take the giant tiles of tile_list (they are the slowest blocks, so they
 // start first), block n_giant + i takes tile i (a giant tile returns at once there): the few giant points run
 // beside the ordinary tiles instead of in a launch of their own.
+template <bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_matvec(int n_giant, const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                    const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
@@ -343,6 +377,7 @@ __global__ __launch_bounds__(256) void k_mf_matvec(int n_giant, const Tile* __re
                                                    const double* __restrict__ ct, const double* __restrict__ cm,
                                                    const double* __restrict__ sc, const double* __restrict__ X,
                                                    const double* __restrict__ ptrec /*[npt][kPtRec]*/,
+                                                   const double* __restrict__ omega,
                                                    const double* __restrict__ x, double* __restrict__ slab /*[rows][9]*/,
                                                    const Ctl* __restrict__ ctl) {
   __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
@@ -350,11 +385,11 @@ __global__ __launch_bounds__(256) void k_mf_matvec(int n_giant, const Tile* __re
   __shared__ double s4[4];
   if (ctl->done) return;
   if ((int)blockIdx.x >= n_giant)
-    mf_matvec_block<false>(blockIdx.x - n_giant, s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X, ptrec,
-                           x, slab);
+    mf_matvec_block<false, LOSS>(blockIdx.x - n_giant, s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X,
+                                 ptrec, omega, x, slab);
   else
-    mf_matvec_block<true>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X, ptrec,
-                          x, slab);
+    mf_matvec_block<true, LOSS>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X,
+                                ptrec, omega, x, slab);
 }
 
 // =============================================================================================
@@ -495,10 +530,12 @@ __device__ __forceinline__ void mf_resid_E(const double* cd, double x0, double x
 // registers; no atomics, no LDS until one cross-lane reduction per segment.  v = r - E z with the point's z from
 // the point-side pass (point record).  Row sg of slab gets the segment's sums; k_cam_reduce64 adds a camera's segments.
 constexpr int kSegObs = 1024;
+template <bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __restrict__ seg /*{cam, first, count, -}*/,
                                                     const int32_t* __restrict__ cmo_pt, const double2* __restrict__ cmo_xy,
                                                     const double* __restrict__ ct, const double* __restrict__ cm,
-                                                    const double* __restrict__ ptrec, double* __restrict__ slab /*[n_seg][64]*/) {
+                                                    const double* __restrict__ ptrec, const Loss loss,
+                                                    double* __restrict__ slab /*[n_seg][64]*/) {
   __shared__ double s_red[4][64 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int sg = blockIdx.x * 4 + wv;
@@ -534,18 +571,26 @@ __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __res
       mf_blocks(cd, q_c[0], q_c[1], q_c[2], xy_c.x, xy_c.y, F, E, r0, r1);
       const double v0 = r0 - (E[0] * q_c[3] + E[1] * q_c[4] + E[2] * q_c[5]);
       const double v1 = r1 - (E[3] * q_c[3] + E[4] * q_c[4] + E[5] * q_c[5]);
+      double Fw[LOSS ? 18 : 1];   // om F: the one weighted factor of F'F, F'v and F'r
+      if (LOSS) {
+        double rho, om;
+        mf_loss(loss, r0 * r0 + r1 * r1, rho, om);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Fw[k] = om * F[k];
+      }
+      const double* Fl = LOSS ? Fw : F;
       int o = 0;
 #pragma unroll
       for (int a = 0; a < 9; ++a)
 #pragma unroll
         for (int b = a; b < 9; ++b) {
-          acc[o] = fma(F[a], F[b], fma(F[9 + a], F[9 + b], acc[o]));
+          acc[o] = fma(Fl[a], F[b], fma(Fl[9 + a], F[9 + b], acc[o]));
           ++o;
         }
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        acc[45 + k] = fma(F[k], v0, fma(F[9 + k], v1, acc[45 + k]));
-        acc[54 + k] = fma(F[k], r0, fma(F[9 + k], r1, acc[54 + k]));
+        acc[45 + k] = fma(Fl[k], v0, fma(Fl[9 + k], v1, acc[45 + k]));
+        acc[54 + k] = fma(Fl[k], r0, fma(Fl[9 + k], r1, acc[54 + k]));
       }
     }
     pt_n = pt_n2; xy_c = xy_n; xy_n = xy_n2;
@@ -578,7 +623,7 @@ __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __res
 // Column scaling is NOT applied to F here (the raw camera sums are scaled by k_cam_reduce64); the point
 // scaling sp enters through mf_point_solve.  partial_cost[tile] = 0.5 sum r^2.
 // ROWS = false: point side only (no F, no camera rows); k_mf_camrows takes X and z from the point records.
-template <bool GIANT, bool ROWS>
+template <bool GIANT, bool ROWS, bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                  const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                  const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
@@ -589,7 +634,8 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
                                                  double* __restrict__ gp, double* __restrict__ dgp /*diag E'E, or null*/,
                                                  double* __restrict__ ptrec, double* __restrict__ slab /*[rows][64]*/,
                                                  double* __restrict__ partial /*[tile][4]: cost, max |g_p|, |g_p|^2*/,
-                                                 Ctl* __restrict__ ctl) {
+                                                 Ctl* __restrict__ ctl, const Loss loss, double* __restrict__ omega /*[slot], LOSS*/) {
+  static_assert(!(ROWS && LOSS), "the loss weights enter the camera rows in k_mf_camrows (two-pass K2 only)");
   __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
   __shared__ double s_acc[(GIANT || !ROWS) ? 1 : kMaxCamSlots * 63];
   __shared__ double s4[4];
@@ -627,7 +673,6 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         mf_read_cam(cd, s_cam, cs);
         if (ROWS) mf_blocks(cd, x0, x1, x2, ox, oy, F, E, r0, r1);
         else mf_resid_E(cd, x0, x1, x2, ox, oy, E, r0, r1);
-        cost += r0 * r0 + r1 * r1;
         v[0] = E[0] * E[0] + E[3] * E[3];
         v[1] = E[1] * E[0] + E[4] * E[3];
         v[2] = E[1] * E[1] + E[4] * E[4];
@@ -637,6 +682,16 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         v[6] = E[0] * r0 + E[3] * r1;
         v[7] = E[1] * r0 + E[4] * r1;
         v[8] = E[2] * r0 + E[5] * r1;
+        if (LOSS) {
+          double rho, om;
+          mf_loss(loss, r0 * r0 + r1 * r1, rho, om);
+          cost += rho;
+          omega[slot] = om;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v[k] *= om;
+        } else {
+          cost += r0 * r0 + r1 * r1;
+        }
       }
       mf_seg_scan3(v[0], v[1], v[2], lane, pos, maxrun);
       mf_seg_scan3(v[3], v[4], v[5], lane, pos, maxrun);
@@ -698,10 +753,19 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
           double cd[kCamLds], F[18], E[6], r0, r1;
           mf_stage_cam_init(cd, ocam[slot], ct, cm);
           mf_blocks(cd, x0, x1, x2, oxy[chunk * (2 * kChunk) + tid], oxy[chunk * (2 * kChunk) + kChunk + tid], F, E, r0, r1);
-          cost += r0 * r0 + r1 * r1;
           v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[1] * E[0] + E[4] * E[3]; v[2] = E[1] * E[1] + E[4] * E[4];
           v[3] = E[2] * E[0] + E[5] * E[3]; v[4] = E[2] * E[1] + E[5] * E[4]; v[5] = E[2] * E[2] + E[5] * E[5];
           v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
+          if (LOSS) {
+            double rho, om;
+            mf_loss(loss, r0 * r0 + r1 * r1, rho, om);
+            cost += rho;
+            omega[slot] = om;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[k] *= om;
+          } else {
+            cost += r0 * r0 + r1 * r1;
+          }
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) a[k] += block_sum(v[k], s4);
@@ -750,7 +814,7 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
 
 // K4-mf: back-substitution  z_p = sp.(C^-1 (g_p - sum E_s' F_s y_c)) = zg - W sum E'u, candidate points
 // Xc = X - z, yp = z / sp, and partial[4*tile + {0,1,2}] = {sum m.(r - m/2), |X - Xc|^2, |Xc|^2}, m = u + E z.
-template <bool GIANT>
+template <bool GIANT, bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                     const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                     const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
@@ -759,7 +823,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
                                                     const double* __restrict__ sc, const double* __restrict__ sp,
                                                     const double* __restrict__ ptrec, const double* __restrict__ yc,
                                                     double* __restrict__ yp, double* __restrict__ Xc,
-                                                    double* __restrict__ partial) {
+                                                    double* __restrict__ partial, const double* __restrict__ omega /*LOSS*/) {
   __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
   __shared__ double s4[4];
   const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
@@ -785,7 +849,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
 #pragma unroll
       for (int k = 0; k < kPtRec; ++k) rec[k] = 0.0;
       MfGeo geo;
-      double u0 = 0, u1 = 0, v0 = 0, v1 = 0, v2 = 0, r0 = 0, r1 = 0;
+      double u0 = 0, u1 = 0, v0 = 0, v1 = 0, v2 = 0, r0 = 0, r1 = 0, om = 1.0;
       if (valid) {
         const double* rp = ptrec + (size_t)kPtRec * p;
 #pragma unroll
@@ -797,6 +861,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         v0 = geo.E[0] * u0 + geo.E[3] * u1;
         v1 = geo.E[1] * u0 + geo.E[4] * u1;
         v2 = geo.E[2] * u0 + geo.E[5] * u1;
+        if (LOSS) { om = omega[slot]; v0 *= om; v1 *= om; v2 *= om; }
         const size_t chunk = slot / kChunk, l = slot % kChunk;
         r0 = geo.f * geo.d * geo.px - oxy[chunk * (2 * kChunk) + l];
         r1 = geo.f * geo.d * geo.py - oxy[chunk * (2 * kChunk) + kChunk + l];
@@ -810,7 +875,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         const double z2 = rec[5] - (rec[9] * a0 + rec[10] * a1 + rec[11] * a2);
         const double m0 = u0 + geo.E[0] * z0 + geo.E[1] * z1 + geo.E[2] * z2;
         const double m1 = u1 + geo.E[3] * z0 + geo.E[4] * z1 + geo.E[5] * z2;
-        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
+        mcc += om * (m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1));
         if (pos == 0) {
           yp[3 * p] = z0 * mf_rcp(sp[3 * p]); yp[3 * p + 1] = z1 * mf_rcp(sp[3 * p + 1]); yp[3 * p + 2] = z2 * mf_rcp(sp[3 * p + 2]);
           const double c0 = rec[0] - z0, c1 = rec[1] - z1, c2 = rec[2] - z2;
@@ -840,6 +905,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
           mf_geom(cd, rec[0], rec[1], rec[2], geo);
           mf_forward(geo, cd, rec[0], rec[1], rec[2], u0, u1);
           v0 = geo.E[0] * u0 + geo.E[3] * u1; v1 = geo.E[1] * u0 + geo.E[4] * u1; v2 = geo.E[2] * u0 + geo.E[5] * u1;
+          if (LOSS) { const double om = omega[slot]; v0 *= om; v1 *= om; v2 *= om; }
         }
         a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
       }
@@ -868,7 +934,7 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         const double m1 = u1 + geo.E[3] * z0 + geo.E[4] * z1 + geo.E[5] * z2;
         const double r0 = geo.f * geo.d * geo.px - oxy[chunk * (2 * kChunk) + tid];
         const double r1 = geo.f * geo.d * geo.py - oxy[chunk * (2 * kChunk) + kChunk + tid];
-        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
+        mcc += (LOSS ? omega[slot] : 1.0) * (m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1));
       }
     }
   }
@@ -887,12 +953,13 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
 // cameras (R, t, f, k1, k2) are staged in LDS, every lane gathers its point and reads its measurement.
 // The first n_giant blocks take the giant tiles of tile_list, block n_giant + i takes tile i.
 constexpr int kCamCost = 16;   // 15 doubles used: 8 x ds_read_b128
+template <bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                  const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                  const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
                                                  const int32_t* __restrict__ tile_cams, const double* __restrict__ oxy,
                                                  const double* __restrict__ ct, const double* __restrict__ X,
-                                                 double* __restrict__ partial_cost) {
+                                                 double* __restrict__ partial_cost, const Loss loss) {
   __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamCost];
   __shared__ double s4[4];
   const bool giant = (int)blockIdx.x < n_giant;
@@ -930,7 +997,9 @@ __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __rest
       const double n = px * px + py * py;
       const double d = 1.0 + n * (cd[13] + cd[14] * n);
       const double r0 = cd[12] * d * px - ox, r1 = cd[12] * d * py - oy;
-      cost += r0 * r0 + r1 * r1;
+      double rho = r0 * r0 + r1 * r1;
+      if (LOSS) { double om; mf_loss(loss, rho, rho, om); }
+      cost += rho;
     }
   } else {
     for (int gi = 0; gi < t.ngrp; ++gi) {
@@ -950,7 +1019,9 @@ __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __rest
         const double n = px * px + py * py;
         const double d = 1.0 + n * (cd[13] + cd[14] * n);
         const double r0 = cd[12] * d * px - oxy[chunk * (2 * kChunk) + tid], r1 = cd[12] * d * py - oxy[chunk * (2 * kChunk) + kChunk + tid];
-        cost += r0 * r0 + r1 * r1;
+        double rho = r0 * r0 + r1 * r1;
+        if (LOSS) { double om; mf_loss(loss, rho, rho, om); }
+        cost += rho;
       }
     }
   }

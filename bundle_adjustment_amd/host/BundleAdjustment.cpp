@@ -219,6 +219,18 @@ void BundleAdjustment::solve() {
     o.parameter_tolerance = options.parameter_tolerance;
     o.eta = options.eta;
     o.max_solver_time_in_seconds = options.max_solver_time_in_seconds;
+    // Loss function of every residual block: the reference passes nullptr to AddResidualBlock (src/BundleAdjustment.cpp:69),
+    // which stays the default.  BA_LOSS=huber:<a> or cauchy:<a> applies ceres::HuberLoss(a) / ceres::CauchyLoss(a) instead
+    // (a in pixels), e.g. for BAL files with mismatched tracks.
+    if (const char *ls = getenv("BA_LOSS")) {
+        const std::string spec(ls);
+        const size_t colon = spec.find(':');
+        const std::string kind = spec.substr(0, colon);
+        if (kind == "huber") o.loss_type = MIBA_LOSS_HUBER;
+        else if (kind == "cauchy") o.loss_type = MIBA_LOSS_CAUCHY;
+        else if (!kind.empty() && kind != "none") throw std::invalid_argument("BA_LOSS: expected huber:<a>, cauchy:<a> or none, got " + spec);
+        if (o.loss_type != MIBA_LOSS_NONE) o.loss_scale = colon == std::string::npos ? 1.0 : std::atof(spec.c_str() + colon + 1);
+    }
 
     // the state may have been edited through the getters since createProblem()
     check(miba_set_state(problem, R, T, intrinsics, X), problem, "miba_set_state");
@@ -255,7 +267,7 @@ void BundleAdjustment::solve() {
                                  : ms.exact_linear_solver
                                        ? "DENSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device)"
                                        : "ITERATIVE_SCHUR (HIP implicit-Schur PCG run to q-tolerance 1e-12 in place of the exact solver: "
-                                         "more than 2048 cameras, or MIBA_DENSE=0 / MIBA_MF=0)";
+                                         "more than 2048 cameras, a loss function, or MIBA_DENSE=0 / MIBA_MF=0)";
 
     std::cout << ceres::LinearSolverTypeToString(options.linear_solver_type) << std::endl;
     std::cout << summary.FullReport() << std::endl;

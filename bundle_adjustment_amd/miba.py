@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MIBA_LIB", os.path.join(_HERE, "libmiba.so"))   # MIB
 (DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR,
  ITERATIVE_SCHUR, CGNR) = range(7)
 PRECOND_JACOBI, PRECOND_SCHUR_JACOBI = 0, 1
+LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2   # options.loss_type (ceres::HuberLoss / CauchyLoss with options.loss_scale)
 CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE = range(5)
 K_EVAL_JAC, K_EVAL_COST, K_SCHUR_INIT, K_SCHUR_MATVEC, K_BACKSUB = range(5)
 K_COUNT = 8
@@ -57,7 +58,8 @@ class Options(C.Structure):
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
                 ("parameter_tolerance", C.c_double), ("eta", C.c_double), ("eta_exact", C.c_double),
-                ("max_solver_time_in_seconds", C.c_double)]
+                ("max_solver_time_in_seconds", C.c_double),
+                ("loss_type", C.c_int32), ("reserved", C.c_int32), ("loss_scale", C.c_double)]
 
 
 class Iteration(C.Structure):

@@ -123,7 +123,16 @@ typedef struct {
   double eta;                               /* 1e-1 */
   double eta_exact;                         /* q-tolerance used for the non-iterative solver types (1e-12) */
   double max_solver_time_in_seconds;        /* 1e9 */
+  /* robust loss applied to every residual block: the LossFunction argument of Problem::AddResidualBlock, for which
+   * the reference passes nullptr (src/BundleAdjustment.cpp:69) = MIBA_LOSS_NONE, the default.  HUBER / CAUCHY are
+   * ceres::HuberLoss(loss_scale) / ceres::CauchyLoss(loss_scale); ITERATIVE_SCHUR + JACOBI only (other linear solver
+   * types run as PCG to eta_exact), matrix-free two-pass kernels only. */
+  int32_t loss_type;
+  int32_t reserved;
+  double loss_scale;                        /* the 'a' of HuberLoss / CauchyLoss, in residual units (pixels) */
 } miba_options;
+
+enum { MIBA_LOSS_NONE = 0, MIBA_LOSS_HUBER = 1, MIBA_LOSS_CAUCHY = 2 };
 
 typedef struct {
   int32_t iteration;

@@ -52,6 +52,8 @@ void bao_default_options(bao_options* o) {
   o->parameter_tolerance = 1e-8;
   o->eta = 1e-1;
   o->cam_const = NULL;
+  o->loss_type = BAO_LOSS_NONE;
+  o->loss_scale = 1.0;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -200,7 +202,27 @@ typedef struct {
   double* tmp2;    /* [2 n_obs] scratch (Ceres' tmp_rows_) */
   unsigned char *cam_active, *pt_active;
   double* tbuf;    /* per-thread camera accumulators: n_thr * 81 * n_cam */
+  int loss_type;   /* BAO_LOSS_*: applied to every residual block */
+  double loss_a;
 } prob_t;
+
+/* ceres::HuberLoss / CauchyLoss ::Evaluate on s = |r|^2: rho(s) and rho'(s) (rho'' <= 0 for both, so Ceres'
+ * Corrector scales residual and Jacobian rows by sqrt(rho') and nothing else) */
+static void loss_eval(int type, double a, double s, double* rho, double* rho1) {
+  const double b = a * a;
+  if (type == BAO_LOSS_HUBER && s > b) {
+    const double r = sqrt(s);
+    *rho = 2.0 * a * r - b;
+    *rho1 = fmax(DBL_MIN, a / r);
+  } else if (type == BAO_LOSS_CAUCHY) {
+    const double sum = 1.0 + s / b;
+    *rho = b * log(sum);
+    *rho1 = fmax(DBL_MIN, 1.0 / sum);
+  } else {
+    *rho = s;
+    *rho1 = 1.0;
+  }
+}
 
 static int prob_build(prob_t* P, int n_cam, int n_pt, int64_t n_obs, const int32_t* obs_cam,
                       const int32_t* obs_pt, const double* obs_xy, int n_thr) {
@@ -277,7 +299,17 @@ static double prob_evaluate(prob_t* P, const double* cams, const double* pts, co
       double* F = P->F + 18 * s;
       double* E = P->E + 6 * s;
       bao_project(cams + 9 * (size_t)c, pts + 3 * (size_t)p, P->oxy + 2 * s, r, F, E);
-      cost += r[0] * r[0] + r[1] * r[1];
+      if (P->loss_type != BAO_LOSS_NONE) {
+        double rho, rho1;
+        loss_eval(P->loss_type, P->loss_a, r[0] * r[0] + r[1] * r[1], &rho, &rho1);
+        const double w = sqrt(rho1);
+        r[0] *= w; r[1] *= w;
+        for (int k = 0; k < 18; ++k) F[k] *= w;
+        for (int k = 0; k < 6; ++k) E[k] *= w;
+        cost += rho;
+      } else {
+        cost += r[0] * r[0] + r[1] * r[1];
+      }
       for (int k = 0; k < 9; ++k) gc[9 * (size_t)c + k] += F[k] * r[0] + F[9 + k] * r[1];
       for (int k = 0; k < 3; ++k) gp[k] += E[k] * r[0] + E[3 + k] * r[1];
       if (sc)
@@ -301,7 +333,9 @@ static double prob_cost(const prob_t* P, const double* cams, const double* pts) 
     for (int64_t s = P->pt_off[p]; s < P->pt_off[p + 1]; ++s) {
       double r[2];
       bao_project(cams + 9 * (size_t)P->cam[s], pts + 3 * (size_t)p, P->oxy + 2 * s, r, NULL, NULL);
-      cost += r[0] * r[0] + r[1] * r[1];
+      double rho = r[0] * r[0] + r[1] * r[1], rho1;
+      if (P->loss_type != BAO_LOSS_NONE) loss_eval(P->loss_type, P->loss_a, rho, &rho, &rho1);
+      cost += rho;
     }
   }
   return 0.5 * cost;
@@ -841,6 +875,7 @@ int bao_linear_step(int n_cam, int n_pt, int64_t n_obs, const double* cams, cons
   schur_t S;
   int rc = prob_build(&P, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, opt->num_threads);
   if (rc) return rc;
+  P.loss_type = opt->loss_type; P.loss_a = opt->loss_scale;
   if (schur_alloc(&S, n_cam, n_pt)) { prob_free(&P); return -1; }
   double* dc = (double*)malloc(sizeof(double) * 9 * ((size_t)n_cam + 1));
   double* dp = (double*)malloc(sizeof(double) * 3 * ((size_t)n_pt + 1));
@@ -872,6 +907,7 @@ int bao_solve(int n_cam, int n_pt, int64_t n_obs, double* cams, double* pts,
   schur_t S;
   int rc = prob_build(&P, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, opt->num_threads);
   if (rc) return rc;
+  P.loss_type = opt->loss_type; P.loss_a = opt->loss_scale;
   if (schur_alloc(&S, n_cam, n_pt)) { prob_free(&P); return -1; }
   const size_t nc9 = 9 * (size_t)n_cam, np3 = 3 * (size_t)n_pt;
   double* xc = (double*)malloc(sizeof(double) * nc9);   /* current x */

@@ -64,7 +64,15 @@ typedef struct {
   /* constant parameter blocks (ceres::Problem::SetParameterBlockConstant, src/BundleAdjustment.cpp:77-79,88-90):
      [n_cam][3] flags for (rotation, translation, intrinsics), non-zero = constant; NULL = all free */
   const unsigned char* cam_const;
+  /* robust loss on every residual block (ceres::LossFunction; the reference passes nullptr, src/BundleAdjustment.cpp:69):
+     BAO_LOSS_* below with scale a; cost = 1/2 sum rho(|r|^2), residual and Jacobian rows corrected as Ceres' Corrector
+     does for rho'' <= 0: both multiplied by sqrt(rho') */
+  int loss_type;
+  double loss_scale;
 } bao_options;
+
+/* ceres::HuberLoss(a): rho(s) = s (s <= a^2), 2 a sqrt(s) - a^2 otherwise; ceres::CauchyLoss(a): a^2 log(1 + s/a^2) */
+enum { BAO_LOSS_NONE = 0, BAO_LOSS_HUBER = 1, BAO_LOSS_CAUCHY = 2 };
 
 typedef struct {
   int iteration;

@@ -63,7 +63,7 @@ def default_options():
                 max_trust_region_radius=1e16, min_trust_region_radius=1e-32,
                 min_relative_decrease=1e-3, min_lm_diagonal=1e-6, max_lm_diagonal=1e32,
                 function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8,
-                max_num_consecutive_invalid_steps=5, cam_const=None)
+                max_num_consecutive_invalid_steps=5, cam_const=None, loss=None)
 
 
 def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
@@ -83,10 +83,30 @@ def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
     def unpack(x):
         return x[np3:].reshape(n_cam, 9), x[:np3].reshape(n_pt, 3)
 
+    # robust loss (ceres::LossFunction on every residual block): loss = ("huber" | "cauchy", a).  Both have
+    # rho'' <= 0, for which Ceres' Corrector multiplies the block's residual and Jacobian rows by sqrt(rho'(s)),
+    # s = |r|^2, and the cost is 1/2 sum rho(s).
+    loss = o.pop("loss", None)
+    weights = [np.ones(2 * obs_cam.shape[0])]   # row weights of the last evaluate()
+
+    def rho(s):
+        if loss is None:
+            return s, np.ones_like(s)
+        kind, a = loss
+        b = a * a
+        if kind == "huber":
+            rt = np.sqrt(np.maximum(s, b))
+            return np.where(s > b, 2 * a * rt - b, s), np.where(s > b, a / rt, 1.0)
+        if kind == "cauchy":
+            return b * np.log1p(s / b), 1.0 / (1.0 + s / b)
+        raise ValueError(kind)
+
     def evaluate(x):
         c, p = unpack(x)
-        r = residuals(c, p, obs_cam, obs_pt, obs_xy).ravel()
-        return 0.5 * r @ r, r
+        r = residuals(c, p, obs_cam, obs_pt, obs_xy)
+        val, d1 = rho((r * r).sum(1))
+        weights[0] = np.repeat(np.sqrt(d1), 2)
+        return 0.5 * val.sum(), r.ravel() * weights[0]
 
     # constant parameter blocks (ceres::Problem::SetParameterBlockConstant, src/BundleAdjustment.cpp:77-79,88-90):
     # cam_const[c] = (rotation, translation, intrinsics) flags; constant columns are removed from the program
@@ -97,8 +117,8 @@ def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
         free[np3:] = ~np.repeat(cc, 3, axis=1).ravel()
     jac_full = jacobian
 
-    def jacobian_free(c, p, oc, op, oxy):
-        return jac_full(c, p, oc, op, oxy)[:, free]
+    def jacobian_free(c, p, oc, op, oxy):   # always called right after evaluate() of the same state
+        return jac_full(c, p, oc, op, oxy)[:, free] * weights[0][:, None]
 
     x = pack(cams, pts)
     radius, decrease_factor, reuse_diag = o["initial_trust_region_radius"], 2.0, False

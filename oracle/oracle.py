@@ -14,6 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libba_oracle.so")
 
 ITERATIVE_SCHUR, DENSE_SCHUR, DENSE_NORMAL = 0, 1, 2
 JACOBI, SCHUR_JACOBI = 0, 1
+LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2
 
 
 class Options(C.Structure):
@@ -37,6 +38,8 @@ class Options(C.Structure):
         ("parameter_tolerance", C.c_double),
         ("eta", C.c_double),
         ("cam_const", C.c_void_p),
+        ("loss_type", C.c_int),
+        ("loss_scale", C.c_double),
     ]
 
 

@@ -44,7 +44,8 @@ def run(rank, world, kind):
     kw = dict(max_num_iterations=6, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
     for name, o in (("it", miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, **kw)),
                     ("sj", miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, preconditioner_type=miba.PRECOND_SCHUR_JACOBI, **kw)),
-                    ("ex", miba.default_options(linear_solver_type=miba.DENSE_SCHUR, **kw))):
+                    ("ex", miba.default_options(linear_solver_type=miba.DENSE_SCHUR, **kw)),
+                    ("hu", miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, loss_type=miba.LOSS_HUBER, loss_scale=1.0, **kw))):
         s.set_state(cams0, pts0)
         its, summ = s.solve(o)
         cams, pts = s.get_state(cams0, pts0)

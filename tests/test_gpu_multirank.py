@@ -2,7 +2,7 @@
 their all-reduces staged through the shared-memory TEST transport (MIBA_TEST_SHM_COMM; RCCL refuses two ranks on
 one device).  Every rank must report what the one-rank run reports: the same PCG iteration counts, accept/reject
 decisions, costs (to summation-order rounding) and final state, for the iterative, SCHUR_JACOBI and exact
-solvers.  What this cannot cover is RCCL itself and xGMI; test_rccl_path_single_rank covers the RCCL calls."""
+solvers and for the iterative solver with a Huber loss.  What this cannot cover is RCCL itself and xGMI; test_rccl_path_single_rank covers the RCCL calls."""
 import os
 import subprocess
 import sys
@@ -83,7 +83,7 @@ def check(ranks, ref, world):
     assert int(out["n_cg"]) == int(ref["n_cg"]) and rel(out["y_cam"], ref["y_cam"]) <= 1e-8 and rel(out["y_pt"], ref["y_pt"]) <= 1e-8
     assert abs(out["mcc"] - ref["mcc"]) <= 1e-10 * abs(ref["mcc"])
     assert abs(out["eval_cost"] - ref["eval_cost"]) <= 1e-12 * ref["eval_cost"] and rel(out["grad_cam"], ref["grad_cam"]) <= 1e-10
-    for name in ("it", "sj", "ex"):
+    for name in ("it", "sj", "ex", "hu"):   # iterative, SCHUR_JACOBI, exact, iterative with a Huber loss
         # iterations are compared while the one-rank run still makes progress: beyond that, accept / reject is
         # decided by rounding noise (same rule as test_lm_trajectory_matches_oracle)
         c = ref[name + "_cost"]

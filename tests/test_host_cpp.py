@@ -133,6 +133,31 @@ def test_app_main_reference_constant_blocks(tmp_path, oracle):
     assert abs(final - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"], (final, osumm)
 
 
+@pytest.mark.gpu
+def test_app_main_with_loss_function(tmp_path, oracle):
+    """BA_LOSS=huber:1.5: the LossFunction argument of AddResidualBlock, nullptr in the reference
+    (src/BundleAdjustment.cpp:69), set to ceres::HuberLoss(1.5) for a file with gross outliers; final cost against
+    the oracle with the same loss."""
+    if os.environ.get("MIBA_MF", "1") == "0" or os.environ.get("MIBA_K2_ONEPASS", "0") == "1":
+        pytest.skip("the loss lives in the two-pass matrix-free kernels")
+    pr = synth.make_problem(20, 600, 2600, seed=5)
+    oxy = pr["obs_xy"].copy()
+    oxy[::8] += np.random.default_rng(2).normal(0, 35.0, oxy[::8].shape)
+    pr = dict(pr, obs_xy=oxy.astype(np.float32).astype(np.float64))
+    path = str(tmp_path / "problem-20-600-pre.txt")
+    synth.write_bal(path, pr)
+    env = dict(os.environ, BA_SIGMA_CAM="0.005", BA_SIGMA_X="0.05", BA_ITERATION_PLY="0", BA_LOSS="huber:1.5")
+    out = subprocess.run([MAIN, path, "ITERATIVE_SCHUR", "10"], capture_output=True, text=True, timeout=120, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    final = float(re.search(r"FINAL_COST (\S+) ITERATIONS (\d+)", out.stdout).group(1))
+    R, T, K, X = oracle.bal_initialize(pr["cams"].astype(np.float32), pr["pts"].astype(np.float32), 0.005, 0.05, seed=1)
+    cams0 = np.concatenate([R, T, K[:, 0:1], K[:, 4:5], K[:, 5:6]], 1)
+    _, _, oits, osumm = oracle.solve(cams0, X, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"],
+                                     oracle.default_options(max_num_iterations=10, linear_solver=oracle.ITERATIVE_SCHUR,
+                                                            loss_type=oracle.LOSS_HUBER, loss_scale=1.5))
+    assert abs(final - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"], (final, osumm)
+
+
 def test_bal_loader_threaded_parse_equals_serial(tmp_path):
     """The multi-threaded from_chars parser against the same parser on one thread, on a file large
     enough (> 1 MiB) to be cut into ranges; also '+'-signed numbers, CRLF line ends and a truncated file."""

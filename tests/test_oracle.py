@@ -184,3 +184,35 @@ def test_schur_jacobi_preconditioner_is_block_diagonal_of_S(oracle):
         assert np.abs(out[pc]["y_cam"] - ex["y_cam"]).max() <= 1e-5 * m
     # (the iteration counts differ but neither is guaranteed smaller: 95 vs 86 here)
     assert out[oracle.SCHUR_JACOBI]["n_cg"] != out[oracle.JACOBI]["n_cg"]
+
+
+@pytest.mark.parametrize("loss", [("huber", 1.0), ("cauchy", 2.0)])
+@pytest.mark.parametrize("solver", ["normal", "schur"])
+def test_robust_loss_matches_numpy_dense_lm(oracle, loss, solver):
+    """Loss functions (ceres::HuberLoss / CauchyLoss on every residual block; the reference passes nullptr,
+    src/BundleAdjustment.cpp:69): the C oracle against the numpy dense restatement on a tiny problem whose
+    every seventh observation is an outlier, so both branches of the Huber function are exercised."""
+    from oracle import dense_lm
+    g, cams0, pts0, oc, op, oxy = _load_lm("lm_tiny_a.json")
+    oxy = oxy.copy()
+    oxy[::7] += np.array([25.0, -40.0])
+    c_ref, p_ref, gold, gsum = dense_lm.solve(cams0, pts0, oc, op, oxy, max_num_iterations=12, loss=loss)
+    o = oracle.default_options(max_num_iterations=12, linear_solver={"normal": oracle.DENSE_NORMAL, "schur": oracle.DENSE_SCHUR}[solver],
+                               loss_type={"huber": oracle.LOSS_HUBER, "cauchy": oracle.LOSS_CAUCHY}[loss[0]], loss_scale=loss[1])
+    cams, pts, its, summ = oracle.solve(cams0, pts0, oc, op, oxy, o)
+    # the loss changes the problem: the plain least-squares cost of the same start is far larger
+    plain = oracle.solve(cams0, pts0, oc, op, oxy, oracle.default_options(max_num_iterations=0))[3]["initial_cost"]
+    assert its[0]["cost"] < 0.5 * plain
+    n_cmp = 1
+    while n_cmp < len(gold) and abs(gold[n_cmp]["cost_change"]) > 1e-8 * gold[n_cmp]["cost"]:
+        n_cmp += 1
+    assert n_cmp >= 3 and len(its) >= n_cmp
+    # the outlier problem is badly conditioned: rounding differences grow by about a digit per iteration, so the
+    # tight comparison covers the first six iterations and the rest is held to 1e-5
+    for k, (a, b) in enumerate(zip(its[:n_cmp], gold[:n_cmp])):
+        assert abs(a["cost"] - b["cost"]) <= (1e-9 if k < 6 else 1e-5) * b["cost"]
+        assert bool(a["step_is_successful"]) == b["step_is_successful"]
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-4 * b["trust_region_radius"]
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-4 * b["gradient_max_norm"] + 1e-9
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-4 * b["step_norm"] + 1e-12
+    assert abs(summ["final_cost"] - gsum["final_cost"]) <= 1e-6 * gsum["final_cost"]
