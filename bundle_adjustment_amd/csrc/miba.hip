@@ -401,8 +401,6 @@ int set_loss(miba_handle h, const miba_options* o) {
   if (!(o->loss_scale > 0.0) || !std::isfinite(o->loss_scale)) return fail(h, MIBA_ERR_INVALID, "loss_scale must be positive and finite");
   if (!h->use_mf || h->k2_onepass)
     return fail(h, MIBA_ERR_INVALID, "a loss function needs the two-pass matrix-free kernels (MIBA_MF=0 or MIBA_K2_ONEPASS=1 is set)");
-  if (o->preconditioner_type == MIBA_PRECOND_SCHUR_JACOBI && o->linear_solver_type == MIBA_ITERATIVE_SCHUR)
-    return fail(h, MIBA_ERR_INVALID, "preconditioner SCHUR_JACOBI is not available together with a loss function");
   if (!h->d_omega) {
     int rc = dev_alloc(h, &h->d_omega, h->n_slots ? h->n_slots : 1);
     if (rc) return rc;
@@ -445,9 +443,12 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
       rc = dev_alloc(h, &h->d_camacc2, (size_t)kK2W * h->n_cam);
       if (rc) return rc;
     }
-    if (h->n_seg)
-      hipLaunchKernelGGL(k_mf_schurdiag, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_ct, h->d_cm,
-                         h->d_ptrec, h->d_slabB);
+    if (h->n_seg && h->loss.type != kLossNone)
+      hipLaunchKernelGGL(k_mf_schurdiag<true>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+    else if (h->n_seg)
+      hipLaunchKernelGGL(k_mf_schurdiag<false>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
     hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_seg_off, h->d_slabB, h->d_sc,
                        h->d_camacc2);
     HIPCHK(h, hipGetLastError());

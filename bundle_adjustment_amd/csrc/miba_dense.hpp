@@ -242,9 +242,12 @@ __global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __r
 // sum over its observations of G' W G (G = E'F unscaled here, the column scale is applied by k_cam_reduce64
 // like for F'F).  Camera-major pass shaped like k_mf_camrows: one wave per segment of one camera, camera record
 // in scalar registers, the 45 upper-triangle sums per lane, one LDS cross-lane reduction.  Row sg of slab.
+// LOSS: G carries the observation's loss weight rho' (E and F each carry its square root), recomputed from the residual.
+template <bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_schurdiag(int n_seg, const int4* __restrict__ seg /*{cam, first, count, -}*/,
-                                                      const int32_t* __restrict__ cmo_pt, const double* __restrict__ ct,
-                                                      const double* __restrict__ cm, const double* __restrict__ ptrec,
+                                                      const int32_t* __restrict__ cmo_pt, const double2* __restrict__ cmo_xy,
+                                                      const double* __restrict__ ct,
+                                                      const double* __restrict__ cm, const double* __restrict__ ptrec, const Loss loss,
                                                       double* __restrict__ slab /*[n_seg][64]*/) {
   __shared__ double s_red[4][64 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -267,6 +270,14 @@ __global__ __launch_bounds__(256) void k_mf_schurdiag(int n_seg, const int4* __r
     const double* rp = ptrec + (size_t)kPtRec * (size_t)pt_c;
     double G[27], T[27];
     dense_obs_G(cd, one, rp[0], rp[1], rp[2], G);
+    if (LOSS) {
+      const double2 xy = cmo_xy[first + i];
+      double E[6], r0, r1, rho, om;
+      mf_resid_E(cd, rp[0], rp[1], rp[2], xy.x, xy.y, E, r0, r1);
+      mf_loss(loss, r0 * r0 + r1 * r1, rho, om);
+#pragma unroll
+      for (int m = 0; m < 27; ++m) G[m] *= om;
+    }
     dense_WG(rp + 6, G, T);
     int o = 0;
 #pragma unroll

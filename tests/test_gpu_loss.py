@@ -104,6 +104,32 @@ def test_lm_trajectory_with_loss_matches_oracle(oracle, outliers, name):
     assert abs(back - summ["final_cost"]) <= 1e-10 * summ["final_cost"]
 
 
+@pytest.mark.parametrize("name", sorted(LOSSES))
+def test_schur_jacobi_with_loss_matches_oracle(oracle, outliers, name):
+    """SCHUR_JACOBI preconditioner (block diagonal of the weighted S, k_mf_schurdiag<LOSS>): same PCG iteration
+    counts and costs as the oracle with the same preconditioner and loss."""
+    pr, cams0, pts0 = outliers
+    kw = dict(max_num_iterations=8, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+    mo, oo = both_options(oracle, name, eta=0.1, **kw)
+    mo.preconditioner_type = miba.PRECOND_SCHUR_JACOBI
+    oo.preconditioner = oracle.SCHUR_JACOBI
+    s = make_solver(pr, cams0, pts0)
+    its, summ = s.solve(mo)
+    s.close()
+    _, _, oits, osumm = oracle.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], oo)
+    n_cmp = 1
+    while n_cmp < len(oits) and abs(oits[n_cmp]["cost_change"]) > 1e-9 * oits[n_cmp]["cost"]:
+        n_cmp += 1
+    assert n_cmp >= 4 and len(its) >= n_cmp
+    for a, b in zip(its[:n_cmp], oits[:n_cmp]):
+        # a rejected candidate can be a wild state (hundreds of times the current cost, points near camera planes)
+        # whose cost is ill-conditioned in the step: 1e-6 there, 1e-9 on accepted states
+        assert abs(a["cost"] - b["cost"]) <= (1e-9 if b["step_is_successful"] or b["iteration"] == 0 else 1e-6) * abs(b["cost"]), (a, b)
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert a["linear_solver_iterations"] == b["linear_solver_iterations"]
+    assert abs(summ["final_cost"] - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"]
+
+
 def test_loss_with_giant_tracks(oracle):
     """a point seen by more cameras than a wavelet holds: the giant-tile branches of K2, K3, K4 and the cost kernel"""
     rng = np.random.default_rng(3)
@@ -164,9 +190,6 @@ def test_loss_option_errors(outliers):
             s.solve(miba.default_options(loss_type=7))
         with pytest.raises(miba.MibaError):
             s.solve(miba.default_options(loss_type=miba.LOSS_HUBER, loss_scale=0.0))
-        with pytest.raises(miba.MibaError):
-            s.solve(miba.default_options(loss_type=miba.LOSS_CAUCHY, linear_solver_type=miba.ITERATIVE_SCHUR,
-                                         preconditioner_type=miba.PRECOND_SCHUR_JACOBI))
         # the handle stays usable
         its, summ = s.solve(miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, max_num_iterations=2))
         assert summ["final_cost"] <= its[0]["cost"]
