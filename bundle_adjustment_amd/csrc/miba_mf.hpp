@@ -222,10 +222,13 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
   const int q1 = min(q + 4, q_last);
   int32_t w_nxt = idxp[(size_t)q1 * kWave];
   int2 m_nxt = wlp[q1];
+  // loss weights rho' ride in the same pipeline as the index words (LOSS only)
+  const double* omp = LOSS ? omega + (size_t)t.slot0 + lane : nullptr;
+  double om_cur = LOSS ? omp[(size_t)q * kWave] : 1.0, om_nxt = LOSS ? omp[(size_t)q1 * kWave] : 1.0;
   // one wavelet: index word w, point record rec (of the lane's point), longest point run maxrun
-  auto wavelet = [&](const double* rec, const int32_t w, const int maxrun, const int qw) {
+  auto wavelet = [&](const double* rec, const int32_t w, const int maxrun, const double om_slot /*loss weight rho'*/) {
     const bool valid = w >= 0;
-    const double om = (LOSS && valid) ? omega[(size_t)t.slot0 + (size_t)qw * kWave + lane] : 1.0;   // loss weight rho'
+    const double om = (LOSS && valid) ? om_slot : 1.0;   // pad slots hold no weight
     const int cs = valid ? ((w >> 8) & 0xFF) : 0, pl = w & 0xFF;
     const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
     MfGeo geo;
@@ -268,8 +271,10 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
       const int q2 = min(q + 8, q_last);
       const int32_t w_n2 = idxp[(size_t)q2 * kWave];
       const int2 m_n2 = wlp[q2];
-      wavelet(rec_a, w_cur, m_cur.y, q);
+      const double om_n2 = LOSS ? omp[(size_t)q2 * kWave] : 1.0;
+      wavelet(rec_a, w_cur, m_cur.y, om_cur);
       w_cur = w_nxt; m_cur = m_nxt; w_nxt = w_n2; m_nxt = m_n2;
+      if (LOSS) { om_cur = om_nxt; om_nxt = om_n2; }
     }
     q += 4;
     if (q >= nwl) break;
@@ -278,8 +283,10 @@ __device__ __forceinline__ void mf_matvec_tile(const Tile& t, const int32_t* __r
       const int q2 = min(q + 8, q_last);
       const int32_t w_n2 = idxp[(size_t)q2 * kWave];
       const int2 m_n2 = wlp[q2];
-      wavelet(rec_b, w_cur, m_cur.y, q);
+      const double om_n2 = LOSS ? omp[(size_t)q2 * kWave] : 1.0;
+      wavelet(rec_b, w_cur, m_cur.y, om_cur);
       w_cur = w_nxt; m_cur = m_nxt; w_nxt = w_n2; m_nxt = m_n2;
+      if (LOSS) { om_cur = om_nxt; om_nxt = om_n2; }
     }
     q += 4;
     if (q >= nwl) break;
