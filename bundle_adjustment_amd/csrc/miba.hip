@@ -627,7 +627,6 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
 // N = 9 n_cam (rounded up to 64) <= kDenseMaxN; MIBA_DENSE=0 keeps the PCG-to-eta_exact stand-in.
 bool dense_wanted(miba_handle h, const miba_options* o) {
   if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR || !h->use_mf) return false;
-  if (o->loss_type != MIBA_LOSS_NONE) return false;   // the dense assembly kernels carry no loss weights: PCG to eta_exact
   const char* e = getenv("MIBA_DENSE");
   if (e && atoi(e) == 0) return false;
   const size_t N = (9 * (size_t)h->n_cam + kNB - 1) / kNB * kNB;
@@ -711,16 +710,25 @@ int dense_assemble(miba_handle h) {
   if (rc) return rc;
   const int N = h->dense_N;
   HIPCHK(h, hipMemsetAsync(h->d_S, 0, ((size_t)N + kNB) * N * sizeof(double), h->st));
-  if (h->dense_planned) {
+  const bool loss = h->loss.type != kLossNone;   // the planned instance lists name no slots, the loss weights are per slot
+  if (h->dense_planned && !loss) {
     if (h->n_dseg)
       hipLaunchKernelGGL(k_dense_blocks, dim3(nblk(h->n_dseg, 4)), dim3(256), 0, h->st, h->n_dseg, h->d_dseg, h->d_dpts, h->d_ct, h->d_cm,
                          h->d_sc, h->d_ptrec, h->d_S, N);
   } else if (h->n_tiles) {
-    hipLaunchKernelGGL(k_dense_pairs, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_tile_cams,
-                       h->d_ct, h->d_cm, h->d_sc, h->d_ptrec, h->d_S, N);
-    if (h->n_giant)
-      hipLaunchKernelGGL(k_dense_pairs_giant, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps,
-                         h->d_idx, h->d_ocam, h->d_ct, h->d_cm, h->d_sc, h->d_ptrec, h->d_S, N);
+#define MIBA_PAIRS_ARGS dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_tile_cams, h->d_ct, h->d_cm, \
+                        h->d_sc, h->d_ptrec, (const double*)h->d_omega, h->d_S, N
+#define MIBA_GIANT_ARGS dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps, h->d_idx, h->d_ocam, h->d_ct, \
+                        h->d_cm, h->d_sc, h->d_ptrec, (const double*)h->d_omega, h->d_S, N
+    if (loss) {
+      hipLaunchKernelGGL(k_dense_pairs<true>, MIBA_PAIRS_ARGS);
+      if (h->n_giant) hipLaunchKernelGGL(k_dense_pairs_giant<true>, MIBA_GIANT_ARGS);
+    } else {
+      hipLaunchKernelGGL(k_dense_pairs<false>, MIBA_PAIRS_ARGS);
+      if (h->n_giant) hipLaunchKernelGGL(k_dense_pairs_giant<false>, MIBA_GIANT_ARGS);
+    }
+#undef MIBA_PAIRS_ARGS
+#undef MIBA_GIANT_ARGS
   }
   HIPCHK(h, hipGetLastError());
   rc = allreduce(h, h->d_S, (size_t)N * N, ncclSum);

@@ -56,11 +56,14 @@ __device__ __forceinline__ void dense_sub_block(double* __restrict__ S, int N, i
 // K5: point side of the explicit Schur complement.  Wavelet layout of K3: a wave owns whole points; lane i
 // visits the other observations of its point by rotating through the run (lane shuffles) and handles the
 // pairs whose camera index is not larger than its own, so only the lower block triangle is written.
+// LOSS: G of every observation carries its loss weight rho' (the per-slot weights K2 has left, miba_mf.hpp); this
+// slot-walking kernel is the assembly used with a loss, because the planned instance lists name no slots.
+template <bool LOSS>
 __global__ __launch_bounds__(256) void k_dense_pairs(const Tile* __restrict__ tiles, const int32_t* __restrict__ idx,
                                                      const int2* __restrict__ wl, const int32_t* __restrict__ tile_cams,
                                                      const double* __restrict__ ct, const double* __restrict__ cm,
                                                      const double* __restrict__ sc, const double* __restrict__ ptrec,
-                                                     double* __restrict__ S, int N) {
+                                                     const double* __restrict__ omega, double* __restrict__ S, int N) {
   __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
   __shared__ double s_sc[kMaxCamSlots * 9];
   __shared__ int s_id[kMaxCamSlots];
@@ -93,6 +96,10 @@ __global__ __launch_bounds__(256) void k_dense_pairs(const Tile* __restrict__ ti
     if (!valid) {
 #pragma unroll
       for (int m = 0; m < 27; ++m) G[m] = 0.0;
+    } else if (LOSS) {
+      const double om = omega[slot];
+#pragma unroll
+      for (int m = 0; m < 27; ++m) G[m] *= om;
     }
     dense_WG(rp + 6, G, T);
     const int cam = valid ? s_id[cs] : -1;
@@ -110,11 +117,13 @@ __global__ __launch_bounds__(256) void k_dense_pairs(const Tile* __restrict__ ti
 }
 
 // giant points (more than 64 observations): the point's chunks against each other through LDS
+template <bool LOSS>
 __global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                            const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                            const int32_t* __restrict__ ocam, const double* __restrict__ ct,
                                                            const double* __restrict__ cm, const double* __restrict__ sc,
-                                                           const double* __restrict__ ptrec, double* __restrict__ S, int N) {
+                                                           const double* __restrict__ ptrec, const double* __restrict__ omega,
+                                                           double* __restrict__ S, int N) {
   __shared__ double s_G[kChunk * 27];
   __shared__ int s_camj[kChunk];
   const Tile t = tiles[tile_list[blockIdx.x]];
@@ -136,6 +145,11 @@ __global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restric
           double cd[kCamLds];
           mf_stage_cam_init(cd, cam_i, ct, cm);
           dense_obs_G(cd, sc + 9 * (size_t)cam_i, x0, x1, x2, Gi);
+          if (LOSS) {
+            const double om = omega[slot_i];
+#pragma unroll
+            for (int m = 0; m < 27; ++m) Gi[m] *= om;
+          }
         }
         dense_WG(rp + 6, Gi, T);
       }
@@ -152,6 +166,11 @@ __global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restric
             double cd[kCamLds];
             mf_stage_cam_init(cd, cam_j, ct, cm);
             dense_obs_G(cd, sc + 9 * (size_t)cam_j, x0, x1, x2, Gj);
+            if (LOSS) {
+              const double om = omega[slot_j];
+#pragma unroll
+              for (int m = 0; m < 27; ++m) Gj[m] *= om;
+            }
           }
 #pragma unroll
           for (int m = 0; m < 27; ++m) s_G[27 * tid + m] = Gj[m];

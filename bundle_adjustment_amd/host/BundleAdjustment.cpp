@@ -267,7 +267,7 @@ void BundleAdjustment::solve() {
                                  : ms.exact_linear_solver
                                        ? "DENSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device)"
                                        : "ITERATIVE_SCHUR (HIP implicit-Schur PCG run to q-tolerance 1e-12 in place of the exact solver: "
-                                         "more than 2048 cameras, a loss function, or MIBA_DENSE=0 / MIBA_MF=0)";
+                                         "more than 2048 cameras, or MIBA_DENSE=0 / MIBA_MF=0)";
 
     std::cout << ceres::LinearSolverTypeToString(options.linear_solver_type) << std::endl;
     std::cout << summary.FullReport() << std::endl;
