@@ -48,6 +48,7 @@ struct DevBuf {
 struct EvPair {
   hipEvent_t a, b;
   int kid;
+  int tag;   // > 0: product of PCG iteration `tag`, classified (worked / returned at once) when the solve knows its length
 };
 
 // TEST transport (MIBA_TEST_SHM_COMM=<name>): the all-reduces of a multi-rank world staged through a POSIX
@@ -147,6 +148,8 @@ struct miba_handle_s {
 
   // kernel timing
   std::vector<EvPair> ev_free, ev_busy;
+  int time_every = 8;            // the product is timed in one PCG iteration out of this many (MIBA_TIME_EVERY)
+  hipEvent_t ev_poll = nullptr;  // marks the device-to-host copy of the PCG control block
   miba_kernel_times kt{};
 };
 
@@ -203,23 +206,41 @@ void free_problem(miba_handle h) {
 }
 
 // ---- kernel timing -------------------------------------------------------------------------
+// Event pairs whose launches have finished are added to the kernel times.  Pairs of PCG products (tag > 0) wait until
+// classify_pcg_events has given them their final kernel id; pairs still in flight stay for the next call.
 void drain_events(miba_handle h) {
+  std::vector<EvPair> keep;
   for (auto& e : h->ev_busy) {
+    if (e.tag > 0) { keep.push_back(e); continue; }
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+    const hipError_t r = hipEventElapsedTime(&ms, e.a, e.b);
+    if (r == hipErrorNotReady) { keep.push_back(e); continue; }
+    if (r == hipSuccess) {
       h->kt.total_ms[e.kid] += ms;
       h->kt.launches[e.kid] += 1;
     }
     h->ev_free.push_back(e);
   }
-  h->ev_busy.clear();
+  (void)hipGetLastError();   // hipErrorNotReady is not an error of the stream
+  h->ev_busy.swap(keep);
+}
+
+// end of a PCG solve of n_it iterations: the timed products of later iterations were enqueued ahead of the host poll
+// and returned at once (ctl->done); they are counted apart from the ones that did the work
+void classify_pcg_events(miba_handle h, int n_it) {
+  for (auto& e : h->ev_busy)
+    if (e.tag > 0) {
+      if (e.tag > n_it) e.kid = MIBA_K_SCHUR_MATVEC_SKIPPED;
+      e.tag = 0;
+    }
 }
 
 struct Timed {
   miba_handle h;
   EvPair e{};
   bool on = false;
-  Timed(miba_handle h_, int kid) : h(h_) {
+  Timed(miba_handle h_, int kid, int tag = 0, bool sample = true) : h(h_) {
+    if (!sample) return;
     if (h->ev_free.empty()) {
       if (h->ev_busy.size() >= 4096) return;  // resolved at the next host sync
       EvPair n{};
@@ -229,6 +250,7 @@ struct Timed {
     e = h->ev_free.back();
     h->ev_free.pop_back();
     e.kid = kid;
+    e.tag = tag;
     on = (hipEventRecord(e.a, h->st) == hipSuccess);
     if (!on) h->ev_free.push_back(e);
   }
@@ -480,10 +502,14 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
 
 // y = S x  (x, y: 9*n_cam device vectors).  ctl: control block whose done flag turns the launch into a no-op;
 // part_xy (matrix-free, single GPU only): per-block partials of x.y from the camera reduction, red_nb entries.
-int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* part_xy) {
+// pcg_iter > 0: the product of that PCG iteration.  An event pair around a launch costs two 6 us bubbles on the
+// stream, so inside the PCG the product is timed in one iteration out of h->time_every only (the first of every solve
+// among them); products outside the PCG (probes, tools) are always timed.
+int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* part_xy, int pcg_iter = 0) {
+  const bool sample = pcg_iter <= 0 || (pcg_iter - 1) % h->time_every == 0;
   if (h->use_mf) {
     if (h->n_tiles) {
-      Timed t(h, MIBA_K_SCHUR_MATVEC);
+      Timed t(h, MIBA_K_SCHUR_MATVEC, pcg_iter, sample);
 #define MIBA_MATVEC_ARGS                                                                                                \
   dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant, h->d_grps,  \
       h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec,        \
@@ -502,7 +528,7 @@ int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* pa
     return allreduce(h, y, 9 * (size_t)h->n_cam + (tail ? (size_t)h->red_nb : 0), ncclSum);
   }
   if (h->n_tiles) {
-    Timed t(h, MIBA_K_SCHUR_MATVEC);
+    Timed t(h, MIBA_K_SCHUR_MATVEC, pcg_iter, sample);
     hipLaunchKernelGGL(k_schur_matvec<0>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
                        h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_J, h->d_Cinv, x, h->d_slab9, nullptr, ctl);
   }
@@ -591,14 +617,16 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
     HIPCHK(h, hipGetLastError());
     Ctl* cur = h->d_ctl + ((j - 1) & 1);   // C_{j-1}: state after the j-1 iterations tested so far
     const int it = j - 1;
-    if (it >= 1 && (it % check_every == 0 || it >= max_it)) {
+    // Host poll: the control block is copied out and marked by an event, iteration j is enqueued behind it, and only
+    // then does the host wait for the copy: the device works on iteration j while the host looks at C_{j-1}, instead
+    // of idling for a host round trip (34 us per poll at Final-13682).  If C_{j-1} says done, iteration j's kernels
+    // return at once, like every launch enqueued past convergence.
+    const bool poll = it >= 1 && (it % check_every == 0 || it >= max_it);
+    if (poll) {
       HIPCHK(h, hipMemcpyAsync(h->h_ctl, cur, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
-      int rc = sync_stream(h);
-      if (rc) return rc;
-      if (h->h_ctl->done) break;
-      if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
+      HIPCHK(h, hipEventRecord(h->ev_poll, h->st));
     }
-    int rc = schur_matvec(h, h->d_pp, h->d_pq, cur, part_pq);
+    int rc = schur_matvec(h, h->d_pp, h->d_pq, cur, part_pq, j);
     if (rc) return rc;
     if (!fused_pq) hipLaunchKernelGGL(pcg_dot, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pp, h->d_pq, cur, part_pq);
     const bool reset = (j % 10 == 0);  // residual_reset_period
@@ -609,15 +637,21 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
       hipLaunchKernelGGL(pcg_update<1>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
                          h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
       HIPCHK(h, hipGetLastError());
-      rc = schur_matvec(h, h->d_px, h->d_pq, cur, nullptr);   // q = S p is dead once x is updated: reuse it for S x
+      rc = schur_matvec(h, h->d_px, h->d_pq, cur, nullptr, j);   // q = S p is dead once x is updated: reuse it for S x
       if (rc) return rc;
       hipLaunchKernelGGL(pcg_update<2>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
                          h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
     }
     HIPCHK(h, hipGetLastError());
+    if (poll) {
+      HIPCHK(h, hipEventSynchronize(h->ev_poll));
+      if (h->h_ctl->done) break;
+      if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
+    }
   }
   *n_it = h->h_ctl->n_it;
   *status = h->h_ctl->status;
+  classify_pcg_events(h, *n_it);
   return MIBA_OK;
 }
 
@@ -964,6 +998,8 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
   if (e == hipSuccess) e = hipStreamCreate(&h->st);
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_scal, 2 * S_COUNT * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming);
+  if (const char* te = getenv("MIBA_TIME_EVERY")) { const int v = atoi(te); if (v >= 1) h->time_every = v; }
   if (e != hipSuccess) {
     int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
     delete h;
@@ -1022,6 +1058,8 @@ int miba_destroy(miba_handle h) {
   free_problem(h);
   drain_events(h);
   for (auto& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : h->ev_busy) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (h->ev_poll) (void)hipEventDestroy(h->ev_poll);
   if (h->comm) (void)ncclCommDestroy(h->comm);
   if (h->shm) {
     h->shm->barrier();   // nobody is inside a reduction any more

@@ -17,6 +17,7 @@ PRECOND_JACOBI, PRECOND_SCHUR_JACOBI = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2   # options.loss_type (ceres::HuberLoss / CauchyLoss with options.loss_scale)
 CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE = range(5)
 K_EVAL_JAC, K_EVAL_COST, K_SCHUR_INIT, K_SCHUR_MATVEC, K_BACKSUB = range(5)
+K_SCHUR_MATVEC_SKIPPED = 5   # timed K3 launches that found the PCG finished and returned at once
 K_COUNT = 8
 
 EXPORTS = [

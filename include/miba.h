@@ -184,12 +184,14 @@ enum {
   MIBA_K_SCHUR_INIT = 2, /* K2  per-point Schur init + camera block sums */
   MIBA_K_SCHUR_MATVEC = 3, /* K3 implicit Schur mat-vec          */
   MIBA_K_BACKSUB = 4,    /* K4  back-substitution + model cost change */
+  MIBA_K_SCHUR_MATVEC_SKIPPED = 5, /* K3 launches enqueued ahead of the host poll that found the PCG finished and returned at once */
   MIBA_K_COUNT = 8
 };
 
 typedef struct {
   int64_t launches[MIBA_K_COUNT];
-  double total_ms[MIBA_K_COUNT];   /* HIP-event time on the launch stream */
+  double total_ms[MIBA_K_COUNT];   /* HIP-event time on the launch stream; inside the PCG the product is timed in one
+                                      iteration out of 8 (MIBA_TIME_EVERY), launches[] counts the timed launches */
   int64_t n_slots;                 /* padded observation slots on this shard */
   int64_t n_obs_local;             /* real observations on this shard */
   int64_t n_pt_local;
