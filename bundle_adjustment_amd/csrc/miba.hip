@@ -603,6 +603,7 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
   double* part_nb = h->d_part_pcg;
   double* part_q = h->d_part_pcg + kPcgMaxBlocks;
   double* part_rho[2] = {h->d_part_pcg + 2 * kPcgMaxBlocks, h->d_part_pcg + 3 * kPcgMaxBlocks};
+  classify_pcg_events(h, 1 << 30);   // pairs a solve that ended in an error has left behind are not kept waiting
   const bool fused_pq = h->use_mf;   // the camera reduction of the matrix-free product leaves the p.q partials
   double* part_pq = fused_pq ? h->d_pq + n : h->d_part_pcg + 4 * kPcgMaxBlocks;   // behind q: one all-reduce for both
   const int n_pq = fused_pq ? h->red_nb : kPcgBlocks;
