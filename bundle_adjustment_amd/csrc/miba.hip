@@ -1319,6 +1319,15 @@ int miba_set_state(miba_handle h, const double* R, const double* T, const double
   if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
   if (!R || !T || !K || !X) return fail(h, MIBA_ERR_INVALID, "null state array");
   HIPCHK(h, hipSetDevice(h->device));
+  // the device camera is BAL-shaped: one focal length, no principal point (src/BalDataloader.cpp:143-148).  Intrinsics
+  // that say otherwise are refused instead of being silently replaced by (f, f, 0, 0) at miba_get_state.
+  for (int c = 0; c < h->n_cam; ++c) {
+    const double* k = K + 6 * (size_t)c;
+    const bool f_differs = k[1] != k[0] && !(std::isnan(k[0]) && std::isnan(k[1]));
+    if (f_differs || (k[2] != 0.0 && !std::isnan(k[2])) || (k[3] != 0.0 && !std::isnan(k[3])))
+      return fail(h, MIBA_ERR_INVALID, "camera %d: intrinsics (fx, fy, ox, oy) = (%g, %g, %g, %g) are not BAL-shaped (fx == fy, ox == oy == 0)",
+                  c, k[0], k[1], k[2], k[3]);
+  }
   std::vector<double> cam(9 * (size_t)h->n_cam);
   for (int c = 0; c < h->n_cam; ++c) {
     double* o = cam.data() + 9 * (size_t)c;
@@ -1366,7 +1375,7 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
     const double* o = cam.data() + 9 * (size_t)c;
     if (R) { R[3 * c] = o[0]; R[3 * c + 1] = o[1]; R[3 * c + 2] = o[2]; }
     if (T) { T[3 * c] = o[3]; T[3 * c + 1] = o[4]; T[3 * c + 2] = o[5]; }
-    if (K) { K[6 * c] = o[6]; K[6 * c + 1] = o[6]; K[6 * c + 2] = 0.0; K[6 * c + 3] = 0.0; K[6 * c + 4] = o[7]; K[6 * c + 5] = o[8]; }
+    if (K) { K[6 * c] = o[6]; K[6 * c + 1] = o[6]; K[6 * c + 4] = o[7]; K[6 * c + 5] = o[8]; }   // ox, oy are not the solver's
   }
   if (!X) return MIBA_OK;
   const size_t n_act = h->plan.pt_orig.size();
@@ -1422,9 +1431,18 @@ int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_ca
   HIPCHK(h, hipSetDevice(h->device));
   miba_options o;
   miba_default_options(&o);
-  int rc = eval_jac(h, h->d_cam, h->d_X, false);
+  int rc;
+  if (residuals || jac_cam || jac_pt || !h->use_mf) {
+    rc = eval_jac(h, h->d_cam, h->d_X, false);
+    h->jac_valid = false;  // d_J now holds the unscaled Jacobian
+  } else {
+    // cost only: the matrix-free residual pass; the stored Jacobian (208 B per slot) is not even allocated
+    const Loss saved_loss = h->loss;
+    h->loss = Loss{kLossNone, 1.0};
+    rc = eval_cost(h, h->d_cam, h->d_X);
+    h->loss = saved_loss;
+  }
   if (rc) return rc;
-  h->jac_valid = false;  // d_J now holds the unscaled Jacobian
   HIPCHK(h, hipMemcpyAsync(h->h_scal, h->d_sum, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
   rc = sync_stream(h);
   if (rc) return rc;
@@ -1452,7 +1470,12 @@ int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_ca
     rc = unit_scale(h);
     if (rc) return rc;
     h->scale_valid = false;
+    // gradient of the plain (unweighted) problem, consistent with the cost, residuals and Jacobians above: a loss left
+    // in the handle by an earlier solve must not weight the sums
+    const Loss saved_loss = h->loss;
+    h->loss = Loss{kLossNone, 1.0};
     rc = schur_init(h, 1e4, &o);   // F'r and E'r do not depend on the radius
+    h->loss = saved_loss;
     if (rc) return rc;
     std::vector<double> acc((size_t)kK2W * h->n_cam), gpv(3 * (size_t)(h->n_pt ? h->n_pt : 1));
     HIPCHK(h, hipMemcpyAsync(acc.data(), h->d_camacc, acc.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
@@ -1728,11 +1751,7 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
         S.termination_type = MIBA_FAILURE;
         snprintf(S.message, sizeof(S.message), "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d",
                  o.max_num_consecutive_invalid_steps);
-        it.trust_region_radius = radius;
-        it.iteration_time_in_seconds = now_s() - t_it;
-        it.cumulative_time_in_seconds = now_s() - t_start - t_callbacks;
-        h->iters.push_back(it);
-        S.num_unsuccessful_steps++;
+        // Ceres returns from here without appending the unfinished iteration to summary.iterations or counting a step
         break;
       }
       radius *= 0.5;  // StepIsInvalid
@@ -1759,15 +1778,7 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
                fabs(it.cost_change) / x_cost, o.function_tolerance);
       converged = true;
     }
-    if (converged) {
-      it.cost = x_cost; it.gradient_max_norm = prev.gradient_max_norm; it.gradient_norm = prev.gradient_norm;
-      it.trust_region_radius = radius;
-      it.iteration_time_in_seconds = now_s() - t_it;
-      it.cumulative_time_in_seconds = now_s() - t_start - t_callbacks;
-      h->iters.push_back(it);
-      S.num_unsuccessful_steps++;
-      break;
-    }
+    if (converged) break;   // as Ceres: the iteration that met the tolerance is neither recorded nor counted
     if (it.relative_decrease > o.min_relative_decrease) {
       // HandleSuccessfulStep: x <- candidate, re-evaluate
       std::swap(h->d_cam, h->d_cam_cand);

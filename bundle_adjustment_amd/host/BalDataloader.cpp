@@ -91,11 +91,11 @@ bool parse_token(const char *b, const char *e, float &out) {
         ++p;
         bool eneg = false;
         if (p < e && (*p == '+' || *p == '-')) { eneg = *p == '-'; ++p; }
-        if (p >= e) return false;
-        for (; p < e && *p >= '0' && *p <= '9'; ++p) { ex = ex * 10 + (*p - '0'); if (ex > 100000) break; }
+        if (p >= e) return parse_float_slow(b, e, out);   // "1e": strtof decides, as for every token off the fast path
+        for (; p < e && *p >= '0' && *p <= '9'; ++p) { ex = ex * 10 + (*p - '0'); if (ex > 100000) return parse_float_slow(b, e, out); }
         if (eneg) ex = -ex;
     }
-    if (p != e) return false;
+    if (p != e) return parse_float_slow(b, e, out);
     if (m == 0) { out = neg ? -0.0f : 0.0f; return true; }
     const int e10 = ex - frac;
     if (e10 < -27 || e10 > 27) return parse_float_slow(b, e, out);

@@ -202,8 +202,11 @@ class Solver:
         except Exception:
             pass
 
-    def set_problem(self, cams, pts, obs_cam, obs_pt, obs_xy):
-        R, T, K = split_cams(cams)
+    def set_problem(self, cams, pts, obs_cam, obs_pt, obs_xy, K=None):
+        """K: optional (n_cam, 6) intrinsics [fx fy ox oy k1 k2] handed over as they are instead of the BAL-shaped ones
+        built from cams"""
+        R, T, Kb = split_cams(cams)
+        K = Kb if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 6)
         X = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
         obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
         obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
@@ -213,8 +216,9 @@ class Solver:
                     _ip(obs_cam), _ip(obs_pt), _dp(obs_xy))
         self._chk(lib().miba_set_problem(self._h, C.byref(p)), "miba_set_problem")
 
-    def set_state(self, cams, pts):
-        R, T, K = split_cams(cams)
+    def set_state(self, cams, pts, K=None):
+        R, T, Kb = split_cams(cams)
+        K = Kb if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 6)
         X = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
         self._chk(lib().miba_set_state(self._h, _dp(R), _dp(T), _dp(K), _dp(X)), "miba_set_state")
 

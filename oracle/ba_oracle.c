@@ -1016,12 +1016,7 @@ int bao_solve(int n_cam, int n_pt, int64_t n_obs, double* cams, double* pts,
     if (!it.step_is_valid) {
       /* HandleInvalidStep */
       if (++consecutive_invalid >= opt->max_num_consecutive_invalid_steps) {
-        termination = BAO_FAILURE;
-        it.cost = x_cost; it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
-        it.trust_region_radius = radius;
-        it.iteration_time_s = now_s() - t_it;
-        if (iters && n_rec < max_iters) iters[n_rec] = it;
-        ++n_rec;
+        termination = BAO_FAILURE;   /* TrustRegionMinimizer returns here: the unfinished iteration is not recorded */
         break;
       }
       radius *= 0.5; /* StepIsInvalid */
@@ -1051,20 +1046,12 @@ int bao_solve(int n_cam, int n_pt, int64_t n_obs, double* cams, double* pts,
     it.cost_change = x_cost - cand_cost;
     it.relative_decrease = it.cost_change / mcc;
     if (it.step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
-      termination = BAO_CONVERGENCE;
-      it.cost = x_cost; it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
-      it.trust_region_radius = radius; it.iteration_time_s = now_s() - t_it;
-      if (iters && n_rec < max_iters) iters[n_rec] = it;
-      ++n_rec;
+      termination = BAO_CONVERGENCE;   /* returns before FinalizeIteration...: not recorded, not counted */
       break;
     }
     /* FunctionToleranceReached */
     if (fabs(it.cost_change) <= opt->function_tolerance * x_cost) {
-      termination = BAO_CONVERGENCE;
-      it.cost = x_cost; it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
-      it.trust_region_radius = radius; it.iteration_time_s = now_s() - t_it;
-      if (iters && n_rec < max_iters) iters[n_rec] = it;
-      ++n_rec;
+      termination = BAO_CONVERGENCE;   /* returns before FinalizeIteration...: not recorded, not counted */
       break;
     }
     if (it.relative_decrease > opt->min_relative_decrease) {

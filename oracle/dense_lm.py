@@ -172,7 +172,7 @@ def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
         if not it["step_is_valid"]:
             invalid += 1
             if invalid >= o["max_num_consecutive_invalid_steps"]:
-                termination = "FAILURE"; its.append(dict(it)); break
+                termination = "FAILURE"; break
             radius *= 0.5
             continue
         invalid = 0
@@ -186,9 +186,9 @@ def solve(cams, pts, obs_cam, obs_pt, obs_xy, **kw):
         it["cost_change"] = x_cost - cand_cost
         it["relative_decrease"] = it["cost_change"] / mcc
         if it["step_norm"] <= o["parameter_tolerance"] * (x_norm + o["parameter_tolerance"]):
-            termination = "CONVERGENCE"; its.append(dict(it)); break
+            termination = "CONVERGENCE"; break
         if abs(it["cost_change"]) <= o["function_tolerance"] * x_cost:
-            termination = "CONVERGENCE"; its.append(dict(it)); break
+            termination = "CONVERGENCE"; break
         if it["relative_decrease"] > o["min_relative_decrease"]:
             x = x_cand
             x_norm = np.linalg.norm(x[free])

@@ -128,3 +128,41 @@ def test_run_to_run_reproducibility(solver):
                 assert a["linear_solver_iterations"] == b["linear_solver_iterations"]
             assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
         assert abs(summ["final_cost"] - summ0["final_cost"]) <= 1e-9 * summ0["final_cost"]
+
+
+def test_intrinsics_that_are_not_bal_shaped_are_refused():
+    """The device camera has one focal length and no principal point (src/BalDataloader.cpp:143-148); fy != fx or a
+    non-zero (ox, oy) is an error, not something miba_get_state silently overwrites."""
+    pr, cams0, pts0 = _tiny()
+    _, _, K = miba.split_cams(cams0)
+    s = miba.Solver(device_id=0)
+    for col, val in ((1, 1.0), (2, 3.5), (3, -2.0)):
+        Kb = K.copy()
+        Kb[2, col] += val
+        with pytest.raises(miba.MibaError):
+            s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], K=Kb)
+    s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    with pytest.raises(miba.MibaError):
+        Kb = K.copy()
+        Kb[0, 3] = 1.0
+        s.set_state(cams0, pts0, K=Kb)
+    cams, _ = s.get_state(cams0, pts0)
+    s.close()
+    assert np.array_equal(cams, cams0)
+
+
+def test_run_that_ends_on_function_tolerance_has_ceres_record_count(oracle):
+    """TrustRegionMinimizer returns from the parameter / function tolerance tests without appending the unfinished
+    iteration to summary.iterations or counting a step: same records and counts as the oracle."""
+    pr, cams0, pts0 = _tiny()
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    its, summ = s.solve(miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, max_num_iterations=50))
+    s.close()
+    _, _, oits, osumm = oracle.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"],
+                                     oracle.default_options(max_num_iterations=50, linear_solver=oracle.DENSE_SCHUR))
+    assert summ["termination_type"] == miba.CONVERGENCE and "tolerance" in summ["message"]
+    assert len(its) == len(oits) == osumm["num_iterations"]
+    assert its[-1]["iteration"] == len(its) - 1
+    assert summ["num_iterations"] == len(its) - 1 == summ["num_successful_steps"] + summ["num_unsuccessful_steps"]
+    assert summ["num_successful_steps"] == osumm["num_successful"] and summ["num_unsuccessful_steps"] == osumm["num_unsuccessful"]

@@ -222,3 +222,23 @@ def test_loss_option_errors(outliers):
         assert summ["final_cost"] <= its[0]["cost"]
     finally:
         s.close()
+
+
+def test_evaluate_after_loss_solve_is_unweighted(oracle, outliers):
+    """miba_evaluate documents cost, residuals, Jacobians and the gradient J'r of the PLAIN problem.  A Huber solve
+    leaves its loss in the handle; the gradient that evaluate() returns afterwards must not carry the weights."""
+    pr, cams0, pts0 = outliers
+    mo, _ = both_options(oracle, "huber", max_num_iterations=3)
+    s = make_solver(pr, cams0, pts0)
+    s.solve(mo)
+    cams, pts = s.get_state(cams0, pts0)
+    ev = s.evaluate(jac=True, grad=True)
+    s.close()
+    ref = oracle.evaluate(cams, pts, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    assert abs(ev["cost"] - ref["cost"]) <= 1e-10 * ref["cost"]
+    assert rel(ev["grad_cam"], ref["grad_cam"]) <= 1e-10
+    assert rel(ev["grad_pt"], ref["grad_pt"]) <= 1e-10
+    # and it is J'r of the blocks the same call returned
+    gc = np.zeros_like(ev["grad_cam"])
+    np.add.at(gc, pr["obs_cam"], np.einsum("oij,oi->oj", ev["Jc"], ev["r"]))
+    assert rel(gc, ev["grad_cam"]) <= 1e-10
