@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -83,12 +84,45 @@ struct ShmComm {
 
 }  // namespace
 
+// ---- static scratch of miba_dense_spd_solve_static (the entry point that allocates nothing) --------------------
+// Layout in doubles: padded matrix [(N + 64) x N] at 0 (N <= kStaticMaxN), the diagonal-block factors at kStaticLdiagOff,
+// the pivot flag (one int32) at kStaticFlagOff.  Every GPU the library runs on holds its own copy of the array until the
+// process ends; in host code the array's NAME is only a stand-in for hipGetSymbolAddress, never a device address.
+constexpr int kStaticMaxN = MIBA_STATIC_SOLVE_MAX_N;
+static_assert(kStaticMaxN % kNB == 0, "static solve limit must be a multiple of the Cholesky block");
+constexpr size_t kStaticLdiagOff = (size_t)(kStaticMaxN + kNB) * kStaticMaxN;
+constexpr size_t kStaticFlagOff = kStaticLdiagOff + (size_t)(kStaticMaxN / kNB) * kLdiag;
+constexpr size_t kStaticDoubles = kStaticFlagOff + 32;
+static __device__ __align__(256) double scratch[kStaticDoubles];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each device, looked up once per device
+
+// device address of this device's copy of the scratch array; the device must be current
+hipError_t static_scratch_for(int dev, double** out) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+  if (!g_scratch_ptr[dev]) {
+    double* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return hipSuccess;
+}
+}  // namespace
+
 struct miba_handle_s {
   miba_config cfg{};
   int device = 0;
   hipStream_t st = nullptr;
   ncclComm_t comm = nullptr;
   ShmComm* shm = nullptr;    // test transport instead of RCCL (see ShmComm)
+  double* static_scratch = nullptr;   // this device's copy of the file-scope scratch array (miba_dense_spd_solve_static)
   std::string err;
   bool has_problem = false;
 
@@ -775,8 +809,9 @@ int dense_assemble(miba_handle h) {
 
 // blocked Cholesky of the lower triangle of A ([N + 64][N], N a multiple of 64, rows N.. zero) and the solve
 // A x = b; x receives the first n_out entries.  *status: 0 ok, 2 a pivot was not positive (A is not SPD).
-int dense_factor_solve(miba_handle h, double* A, int N, double* Ldiag, const double* b, int n_b, double* x, int n_out,
-                       int32_t* d_flag, int* status) {
+// launches only: no allocation, no host synchronisation (shared by the static entry point)
+int dense_factor_enqueue(miba_handle h, double* A, int N, double* Ldiag, const double* b, int n_b, double* x, int n_out,
+                         int32_t* d_flag) {
   HIPCHK(h, hipMemsetAsync(d_flag, 0, sizeof(int32_t), h->st));
   hipLaunchKernelGGL(k_dense_rhs, dim3(nblk(N, 256)), dim3(256), 0, h->st, n_b, N, b, A);
   const int nb = N / kNB;
@@ -793,6 +828,13 @@ int dense_factor_solve(miba_handle h, double* A, int N, double* Ldiag, const dou
                        n_out);
   }
   HIPCHK(h, hipGetLastError());
+  return MIBA_OK;
+}
+
+int dense_factor_solve(miba_handle h, double* A, int N, double* Ldiag, const double* b, int n_b, double* x, int n_out,
+                       int32_t* d_flag, int* status) {
+  int rc0 = dense_factor_enqueue(h, A, N, Ldiag, b, n_b, x, n_out, d_flag);
+  if (rc0) return rc0;
   int32_t flag = 0;
   HIPCHK(h, hipMemcpyAsync(&flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->st));
   if (h->d_ctl) HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));   // Schur-init failure flag
@@ -1000,6 +1042,7 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_scal, 2 * S_COUNT * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl));
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming);
+  if (e == hipSuccess) e = static_scratch_for(dev, &h->static_scratch);   // device `dev` is current here
   if (const char* te = getenv("MIBA_TIME_EVERY")) { const int v = atoi(te); if (v >= 1) h->time_every = v; }
   if (e != hipSuccess) {
     int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
@@ -1592,6 +1635,29 @@ int miba_dense_spd_solve(miba_handle h, int32_t n, const double* A, const double
   cleanup();
   *status = st;
   return rc;
+}
+
+int miba_dense_spd_solve_static(miba_handle h, int32_t n, const double* d_A, const double* d_b, double* d_x, int32_t* d_status) {
+  if (!h || n < 1 || !d_A || !d_b || !d_x || !d_status) return fail(h, MIBA_ERR_INVALID, "bad argument");
+  const size_t N = ((size_t)n + kNB - 1) / kNB * kNB;
+  if (N > (size_t)kStaticMaxN)
+    return fail(h, MIBA_ERR_LIMIT, "n = %d exceeds the static scratch of miba_dense_spd_solve_static (n <= %d); use miba_dense_spd_solve", n, kStaticMaxN);
+  if (!h->static_scratch) return fail(h, MIBA_ERR_HIP, "static scratch address was not resolved at miba_create");
+  HIPCHK(h, hipSetDevice(h->device));
+  // everything below goes through the device address looked up at miba_create, never through the array's name
+  double* S = h->static_scratch;
+  double* Ldiag = h->static_scratch + kStaticLdiagOff;
+  int32_t* flag = (int32_t*)(h->static_scratch + kStaticFlagOff);
+  // the array keeps the last call's contents: the whole [(N + 64) x N] image is rewritten (matrix, identity on the
+  // padding, zero rows below), the factors are rewritten block by block by the panel kernel, the flag is cleared
+  hipLaunchKernelGGL(k_dense_pad, dim3(nblk((N + kNB) * N, 256)), dim3(256), 0, h->st, n, (int)N, d_A, S);
+  HIPCHK(h, hipGetLastError());
+  int rc = dense_factor_enqueue(h, S, (int)N, Ldiag, d_b, n, d_x, n, flag);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_dense_status, dim3(1), dim3(1), 0, h->st, (const int32_t*)flag, d_status);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return MIBA_OK;
 }
 
 int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* avg_ms) {

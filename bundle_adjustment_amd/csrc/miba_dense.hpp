@@ -489,4 +489,18 @@ __global__ void k_dense_rhs(int n, int N, const double* __restrict__ v, double* 
   if (i < N) S[(size_t)N * N + i] = (i < n) ? v[i] : 0.0;
 }
 
+// padded image of a caller's n x n matrix: [(N + 64) x N], identity on the padding diagonal, zero rows below
+__global__ void k_dense_pad(int n, int N, const double* __restrict__ A, double* __restrict__ S) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)(N + kNB) * N) return;
+  const int r = (int)(i / N), c = (int)(i % N);
+  double v = 0.0;
+  if (r < n && c < n) v = A[(size_t)r * n + c];
+  else if (r < N && r == c) v = 1.0;
+  S[i] = v;
+}
+
+// status word of the factorisation as the ABI reports it: 0 ok, 2 a pivot was not positive
+__global__ void k_dense_status(const int32_t* __restrict__ flag, int32_t* __restrict__ status) { *status = *flag ? 2 : 0; }
+
 }  // namespace miba

@@ -25,8 +25,9 @@ EXPORTS = [
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
     "miba_plan_shards", "miba_plan_point_owner", "miba_time_matvec", "miba_set_constant_blocks",
-    "miba_get_reduced_system", "miba_dense_spd_solve",
+    "miba_get_reduced_system", "miba_dense_spd_solve", "miba_dense_spd_solve_static",
 ]
+STATIC_SOLVE_MAX_N = 1024   # MIBA_STATIC_SOLVE_MAX_N of include/miba.h
 
 
 class MibaError(RuntimeError):
@@ -302,6 +303,12 @@ class Solver:
         st = C.c_int32()
         self._chk(lib().miba_dense_spd_solve(self._h, C.c_int32(n), _dp(A), _dp(b), _dp(x), C.byref(st)), "miba_dense_spd_solve")
         return x, st.value
+
+    def dense_spd_solve_static(self, n, d_A, d_b, d_x, d_status):
+        """miba_dense_spd_solve_static: the four arguments are DEVICE addresses (ints) on this handle's GPU; the library
+        allocates nothing (static scratch).  n <= STATIC_SOLVE_MAX_N."""
+        self._chk(lib().miba_dense_spd_solve_static(self._h, C.c_int32(n), C.c_void_p(d_A), C.c_void_p(d_b), C.c_void_p(d_x),
+                                                    C.c_void_p(d_status)), "miba_dense_spd_solve_static")
 
     def kernel_times(self):
         kt = KernelTimes()

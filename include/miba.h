@@ -259,6 +259,18 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
 int miba_get_reduced_system(miba_handle h, double* S_out);
 int miba_dense_spd_solve(miba_handle h, int32_t n, const double* A, const double* b, double* x, int32_t* status);
 
+/* miba_dense_spd_solve_static: NO COUNTERPART IN THE REFERENCE.  The same factorisation as miba_dense_spd_solve for
+ * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It calls no hipMalloc / hipFree / allocating routine: the padded matrix, the diagonal-block
+ * factors and the pivot flag live in a file-scope static __device__ array of the library (9.4 MB, held by every GPU
+ * the library runs on until the process ends), whose device address is resolved once per device at miba_create.
+ * All four pointers are DEVICE pointers on the handle's GPU: A (n x n row-major, lower triangle read), b (n),
+ * x (n, output), status (one int32, output: 0, or 2 when a pivot was not positive).  n <= MIBA_STATIC_SOLVE_MAX_N,
+ * larger sizes are refused with MIBA_ERR_LIMIT.  The work runs on the handle's stream and has finished on return.
+ * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two handles, two threads) race. */
+#define MIBA_STATIC_SOLVE_MAX_N 1024
+int miba_dense_spd_solve_static(miba_handle h, int32_t n, const double* d_A, const double* d_b, double* d_x, int32_t* d_status);
+
 /* Measurement hook: average time of `reps` back-to-back implicit-Schur products S*probe (K3 plus its
  * camera reduction) at the state prepared by the last miba_linear_step. probe has 9*n_cam entries. */
 int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* avg_ms);
