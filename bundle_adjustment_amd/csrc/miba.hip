@@ -249,7 +249,7 @@ void drain_events(miba_handle h) {
     float ms = 0.f;
     const hipError_t r = hipEventElapsedTime(&ms, e.a, e.b);
     if (r == hipErrorNotReady) { keep.push_back(e); continue; }
-    if (r == hipSuccess) {
+    if (r == hipSuccess && e.kid >= 0) {
       h->kt.total_ms[e.kid] += ms;
       h->kt.launches[e.kid] += 1;
     }
@@ -264,7 +264,7 @@ void drain_events(miba_handle h) {
 void classify_pcg_events(miba_handle h, int n_it) {
   for (auto& e : h->ev_busy)
     if (e.tag > 0) {
-      if (e.tag > n_it) e.kid = MIBA_K_SCHUR_MATVEC_SKIPPED;
+      if (e.tag > n_it) e.kid = (e.kid == MIBA_K_SCHUR_MATVEC) ? MIBA_K_SCHUR_MATVEC_SKIPPED : -1;   // -1: not counted
       e.tag = 0;
     }
 }
@@ -397,6 +397,18 @@ constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 +
 // K2-mf over all tiles of this shard (camera tables of the current state must be in d_ct / d_cm):
 // per-point blocks, raw camera slab rows, cost -> d_sum[S_COST] (all-reduced)
 int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want_diag, bool reduce_cost = true) {
+  // the point side (K2a) and the camera side (K2b) are timed apart: MIBA_K_SCHUR_INIT / MIBA_K_SCHUR_INIT_CAM
+  auto camrows = [&]() {
+    if (!h->n_seg) return;
+    Timed t(h, MIBA_K_SCHUR_INIT_CAM);
+    if (h->loss.type != kLossNone)
+      hipLaunchKernelGGL(k_mf_camrows<true>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+    else
+      hipLaunchKernelGGL(k_mf_camrows<false>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+  };
+  bool two_pass = false;
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
 #define MIBA_INIT_ARGS(list)                                                                                              \
@@ -409,9 +421,7 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want
                          MIBA_INIT_ARGS((const int32_t*)nullptr));
       if (h->n_giant)
         hipLaunchKernelGGL((k_mf_init<true, false, true>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
-      if (h->n_seg)
-        hipLaunchKernelGGL(k_mf_camrows<true>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
-                           h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+      two_pass = true;
     } else if (h->k2_onepass) {
       hipLaunchKernelGGL((k_mf_init<false, true, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
                          MIBA_INIT_ARGS((const int32_t*)nullptr));
@@ -423,12 +433,11 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want
                          MIBA_INIT_ARGS((const int32_t*)nullptr));
       if (h->n_giant)
         hipLaunchKernelGGL((k_mf_init<true, false, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
-      if (h->n_seg)
-        hipLaunchKernelGGL(k_mf_camrows<false>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
-                           h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+      two_pass = true;
     }
 #undef MIBA_INIT_ARGS
   }
+  if (two_pass) camrows();
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 0, 0, h->d_sum + S_COST);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 1, 1, h->d_max + S_GMAX_P);
@@ -552,8 +561,11 @@ int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* pa
       else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
 #undef MIBA_MATVEC_ARGS
     }
-    hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
-                       h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, part_xy, ctl);
+    {
+      Timed t(h, MIBA_K_CAM_REDUCE, pcg_iter, sample && pcg_iter > 0);
+      hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
+                         h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, part_xy, ctl);
+    }
     HIPCHK(h, hipGetLastError());
     // x.y is linear in y, so with several ranks the per-block partials of x.y_local are all-reduced together with
     // y_local (the caller places them right behind y): every rank then sums the same red_nb numbers

@@ -18,6 +18,8 @@ LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2   # options.loss_type (ceres::Huber
 CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE = range(5)
 K_EVAL_JAC, K_EVAL_COST, K_SCHUR_INIT, K_SCHUR_MATVEC, K_BACKSUB = range(5)
 K_SCHUR_MATVEC_SKIPPED = 5   # timed K3 launches that found the PCG finished and returned at once
+K_SCHUR_INIT_CAM = 6         # K2b camera side of the Schur init (K_SCHUR_INIT is the point side K2a)
+K_CAM_REDUCE = 7             # camera-side sum of a product, sampled like K3
 K_COUNT = 8
 
 EXPORTS = [

@@ -186,6 +186,8 @@ enum {
   MIBA_K_SCHUR_MATVEC = 3, /* K3 implicit Schur mat-vec          */
   MIBA_K_BACKSUB = 4,    /* K4  back-substitution + model cost change */
   MIBA_K_SCHUR_MATVEC_SKIPPED = 5, /* K3 launches enqueued ahead of the host poll that found the PCG finished and returned at once */
+  MIBA_K_SCHUR_INIT_CAM = 6, /* K2b camera side of the Schur init (k_mf_camrows); MIBA_K_SCHUR_INIT is then the point side K2a */
+  MIBA_K_CAM_REDUCE = 7,   /* camera-side sum of a product (k_cam_reduce_mf), sampled like K3 */
   MIBA_K_COUNT = 8
 };
 
