@@ -45,6 +45,9 @@ def main():
                     help="PCG preconditioner; jacobi is Ceres' default and what the reference runs with")
     ap.add_argument("--loss", default="none", help="none (what the reference runs with), huber:<a> or cauchy:<a>: robust loss on every "
                     "residual block (SURVEY 8f rank 4); not the headline configuration")
+    ap.add_argument("--single-process", action="store_true", help="with --gpus N and no torch.distributed.run: one process drives the N GPUs "
+                    "through one handle (miba_create_multi)")
+    ap.add_argument("--same-device", action="store_true", help="with --single-process: every rank on device 0 (rehearsal)")
     ap.add_argument("--ttt", type=int, default=80, help="also report time-to-cost-tolerance over at most this many LM iterations")
     args = ap.parse_args()
 
@@ -75,27 +78,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % args.gpus)
-    # Rehearsal on ONE GPU (RCCL refuses two ranks on a device): with MIBA_TEST_SHM_COMM set, libmiba's all-reduces go
-    # through its shared-memory test transport, torch.distributed uses gloo and every rank uses device 0.  The numbers
-    # of such a run mean nothing; it exists so that this script's multi-rank control flow can be run before the driver does.
-    rehearsal = world > 1 and bool(os.environ.get("MIBA_TEST_SHM_COMM"))
-    if rehearsal:
-        local_rank = 0
+    single_process = args.single_process and world == 1 and args.gpus > 1
+    if args.gpus > 1 and world == 1 and not single_process:
+        raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU), or --single-process" % args.gpus)
     torch.cuda.set_device(local_rank)
-    dist_dev = "cpu" if rehearsal else "cuda"
+    dist_dev = "cuda"
     uid = None
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo" if rehearsal else "nccl")
-        if not rehearsal:
-            t = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                t.copy_(torch.frombuffer(bytearray(miba.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(t, 0)
-            uid = bytes(t.cpu().numpy().tobytes())
+        dist.init_process_group(backend="nccl")
+        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(miba.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        uid = bytes(t.cpu().numpy().tobytes())
 
     n_cam, n_pt, n_obs, seed = synth.CONFIGS[args.config]
     t0 = time.time()
@@ -103,7 +100,12 @@ def main():
     cams0, pts0 = synth.perturb(pr, args.sigma_cam, args.sigma_x, seed=seed + 1)
     t_gen = time.time() - t0
 
-    solver = miba.Solver(device_id=local_rank, rank=rank, world_size=world, unique_id=uid)
+    if single_process:
+        # ONE process, one handle for all GPUs (miba_create_multi: what app/ba_main uses with BA_NUM_GPUS); --same-device puts
+        # every rank on device 0 (a rehearsal of the control flow on a one-GPU box; its numbers mean nothing)
+        solver = miba.Solver(devices=[0] * args.gpus if args.same_device else list(range(args.gpus)))
+    else:
+        solver = miba.Solver(device_id=local_rank, rank=rank, world_size=world, unique_id=uid)
     t0 = time.time()
     solver.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
     t_setup = time.time() - t0

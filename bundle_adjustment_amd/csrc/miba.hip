@@ -8,10 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
-#include <fcntl.h>
 #include <sched.h>
-#include <sys/mman.h>
-#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -20,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -30,6 +28,7 @@
 #include "miba_mf.hpp"
 #include "miba_dense.hpp"
 #include "miba_plan.hpp"
+#include "miba_comm.hpp"
 
 using namespace miba;
 
@@ -52,33 +51,45 @@ struct EvPair {
   int tag;   // > 0: product of PCG iteration `tag`, classified (worked / returned at once) when the solve knows its length
 };
 
-// TEST transport (MIBA_TEST_SHM_COMM=<name>): the all-reduces of a multi-rank world staged through a POSIX
-// shared-memory segment between processes, so that the whole multi-rank control flow (sharding, what is
-// reduced when, identical decisions on every rank) can be run and checked with several processes on ONE GPU,
-// where RCCL refuses to put two ranks.  Blocking and slow by design; never used unless the variable is set.
-constexpr size_t kShmChunk = (size_t)1 << 19;   // doubles per rank slot (4 MiB)
-struct ShmHeader {
-  std::atomic<int> count;
-  std::atomic<int> gen;
-  char pad[56];
-};
-struct ShmComm {
-  std::string name;
-  void* base = nullptr;
-  size_t bytes = 0;
-  int world = 0, rank = 0;
-  std::vector<double> host;
-  ShmHeader* hdr() { return (ShmHeader*)base; }
-  double* slot(int r) { return (double*)((char*)base + sizeof(ShmHeader)) + (size_t)r * kShmChunk; }
-  void barrier() {
-    ShmHeader* H = hdr();
-    const int g = H->gen.load(std::memory_order_acquire);
-    if (H->count.fetch_add(1, std::memory_order_acq_rel) + 1 == world) {
-      H->count.store(0, std::memory_order_relaxed);
-      H->gen.store(g + 1, std::memory_order_release);
-    } else {
-      while (H->gen.load(std::memory_order_acquire) == g) sched_yield();
+// ---- single-process multi-device group ------------------------------------------------------------------------
+// One handle drives 1..8 GPUs from one process (SURVEY 8b "Threading"): the group handle owns one rank handle per
+// device and runs every entry point on one host thread per rank (rank 0 on the caller's thread).  The ranks are the
+// same code as the one-process-per-GPU ranks; only the transport of allreduce() differs:
+//   kCommRccl  RCCL communicators of ncclCommInitAll (the default for distinct devices)
+//   kCommPeer  the library's own all-reduce: a 2-hop reduce-scatter + all-gather kernel over peer-mapped, fine-grained
+//              staging buffers, rank-ordered sums, every rank receives the same bits
+//   kCommHost  staged through host memory by the rank threads (no peer access needed; the default when a device id
+//              repeats, which RCCL refuses)
+enum { kCommRccl = 0, kCommPeer = 1, kCommHost = 2 };
+struct RankGroup {
+  int n = 0;
+  int mode = kCommRccl;
+  std::vector<miba_handle> sub;
+  std::atomic<int> bar_count{0}, bar_gen{0}, abort{0};
+  // kCommHost: per-rank pinned staging (kPeerChunk doubles) and the combined result
+  std::vector<double*> hbuf;
+  // kCommPeer: per rank, fine-grained device memory: [in | out] staging halves and the signal block
+  std::vector<double*> pstage;
+  std::vector<PeerSignals*> psig;
+  // decisions of rank 0 handed to the other ranks once per LM iteration (callback result, time limit)
+  std::atomic<int> ctl_stop[2];
+  // spin barrier of the rank threads; fails (instead of hanging) when a rank has left with an error
+  int barrier() {
+    const int g = bar_gen.load(std::memory_order_acquire);
+    if (bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      bar_count.store(0, std::memory_order_relaxed);
+      bar_gen.store(g + 1, std::memory_order_release);
+      return 0;
     }
+    const double t0 = now_s();
+    for (long spins = 0; bar_gen.load(std::memory_order_acquire) == g; ++spins) {
+      if (abort.load(std::memory_order_acquire)) return -1;
+      if ((spins & 1023) == 1023) {
+        if (now_s() - t0 > 120.0) { abort.store(1); return -1; }
+        sched_yield();
+      }
+    }
+    return 0;
   }
 };
 
@@ -121,12 +132,15 @@ struct miba_handle_s {
   int device = 0;
   hipStream_t st = nullptr;
   ncclComm_t comm = nullptr;
-  ShmComm* shm = nullptr;    // test transport instead of RCCL (see ShmComm)
+  RankGroup* grp = nullptr;  // rank handle of a single-process multi-device group: the group it belongs to
+  RankGroup* owned = nullptr;  // group handle (what miba_create_multi returns): the group it owns; it has no device state
+  uint32_t peer_epoch = 0;   // kCommPeer: all-reduces issued so far (identical on every rank)
   double* static_scratch = nullptr;   // this device's copy of the file-scope scratch array (miba_dense_spd_solve_static)
   std::string err;
   bool has_problem = false;
 
-  Plan plan;                 // global plan (host)
+  std::shared_ptr<Plan> plan_sp = std::make_shared<Plan>();   // global plan (host); shared by the ranks of a group
+  Plan& plan_ref() { return *plan_sp; }
   // local shard extents
   int64_t t0 = 0, t1 = 0;    // tiles
   int64_t slot_base = 0, n_slots = 0, n_obs_local = 0;
@@ -304,37 +318,91 @@ int sync_stream(miba_handle h) {
 // blocks for n items; never 0 (an empty shard still launches one block whose bounds checks do nothing)
 inline int nblk(size_t n, int bs) { return n ? (int)((n + bs - 1) / bs) : 1; }
 
-int allreduce_shm(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
-  ShmComm& C = *h->shm;
-  C.host.resize(kShmChunk);
-  for (size_t o = 0; o < n; o += kShmChunk) {
-    const size_t m = std::min(kShmChunk, n - o);
-    HIPCHK(h, hipMemcpyAsync(C.host.data(), buf + o, m * sizeof(double), hipMemcpyDeviceToHost, h->st));
+// kCommHost: every rank thread copies its piece to pinned host memory, the threads meet, every rank combines the pieces
+// in rank order (the same bits everywhere) and copies the result back.  Blocking; needs no peer access.
+int allreduce_host(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
+  RankGroup& G = *h->grp;
+  const int r = h->cfg.rank;
+  for (size_t o = 0; o < n; o += kPeerChunk) {
+    const size_t m = std::min(kPeerChunk, n - o);
+    HIPCHK(h, hipMemcpyAsync(G.hbuf[r], buf + o, m * sizeof(double), hipMemcpyDeviceToHost, h->st));
     HIPCHK(h, hipStreamSynchronize(h->st));
-    memcpy(C.slot(C.rank), C.host.data(), m * sizeof(double));
-    C.barrier();
-    // every rank combines the slots in rank order: the same bits everywhere
+    if (G.barrier()) return fail(h, MIBA_ERR_RCCL, "a rank of the group left a reduction (see its error)");
+    double* out = G.hbuf[G.n + r];
     for (size_t i = 0; i < m; ++i) {
-      double v = C.slot(0)[i];
-      for (int r = 1; r < C.world; ++r) v = (op == ncclMax) ? std::max(v, C.slot(r)[i]) : v + C.slot(r)[i];
-      C.host[i] = v;
+      double v = G.hbuf[0][i];
+      for (int q = 1; q < G.n; ++q) v = (op == ncclMax) ? std::max(v, G.hbuf[q][i]) : v + G.hbuf[q][i];
+      out[i] = v;
     }
-    C.barrier();
-    HIPCHK(h, hipMemcpyAsync(buf + o, C.host.data(), m * sizeof(double), hipMemcpyHostToDevice, h->st));
+    if (G.barrier()) return fail(h, MIBA_ERR_RCCL, "a rank of the group left a reduction (see its error)");
+    HIPCHK(h, hipMemcpyAsync(buf + o, out, m * sizeof(double), hipMemcpyHostToDevice, h->st));
     HIPCHK(h, hipStreamSynchronize(h->st));
   }
   return MIBA_OK;
 }
 
+// kCommPeer: the 2-hop kernel of miba_comm.hpp, stream-ordered, no host synchronisation
+int allreduce_peer(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
+  RankGroup& G = *h->grp;
+  PeerArgs A{};
+  for (int q = 0; q < G.n; ++q) { A.stage[q] = G.pstage[q]; A.sig[q] = G.psig[q]; }
+  A.n_ranks = G.n;
+  A.rank = h->cfg.rank;
+  A.op_max = (op == ncclMax) ? 1 : 0;
+  for (size_t o = 0; o < n; o += kPeerChunk) {
+    const size_t m = std::min(kPeerChunk, n - o);
+    A.epoch = ++h->peer_epoch;
+    hipLaunchKernelGGL(k_peer_allreduce, dim3(kPeerBlocks), dim3(256), 0, h->st, A, buf + o, m);
+    HIPCHK(h, hipGetLastError());
+  }
+  return MIBA_OK;
+}
+
 int allreduce(miba_handle h, double* buf, size_t n, ncclRedOp_t op) {
-  if (h->shm) return allreduce_shm(h, buf, n, op);
+  if (h->grp && h->grp->mode == kCommHost) return allreduce_host(h, buf, n, op);
+  if (h->grp && h->grp->mode == kCommPeer) return allreduce_peer(h, buf, n, op);
   if (!h->comm) return MIBA_OK;
   NCCLCHK(h, ncclAllReduce(buf, buf, n, ncclDouble, op, h->comm, h->st));
   return MIBA_OK;
 }
 
-// more than one rank contributes to the sums (RCCL or the test transport)
-inline bool multi_rank(miba_handle h) { return h->comm != nullptr || h->shm != nullptr; }
+// more than one rank contributes to the sums
+inline bool multi_rank(miba_handle h) { return h->comm != nullptr || (h->grp && h->grp->n > 1); }
+
+// fn(rank handle, rank) on one host thread per rank, rank 0 on the caller's thread.  A rank that fails raises the
+// group's abort flag so that the others leave their barriers instead of waiting for it.
+template <typename F>
+int group_run(miba_handle g, F fn) {
+  RankGroup& G = *g->owned;
+  G.abort.store(0);
+  std::vector<int> rc(G.n, 0);
+  std::vector<std::thread> th;
+  for (int r = 1; r < G.n; ++r)
+    th.emplace_back([&, r] {
+      rc[r] = fn(G.sub[r], r);
+      if (rc[r]) G.abort.store(1);
+    });
+  rc[0] = fn(G.sub[0], 0);
+  if (rc[0]) G.abort.store(1);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < G.n; ++r)
+    if (rc[r]) {
+      g->err = "rank " + std::to_string(r) + ": " + G.sub[r]->err;
+      g_last_error = g->err;
+      return rc[r];
+    }
+  return MIBA_OK;
+}
+
+// once per LM iteration: rank 0's verdict (callback result, time limit) reaches every rank of a group
+int group_exchange_stop(miba_handle h, int iteration, int* code) {
+  if (!h->grp || h->grp->n < 2) return MIBA_OK;
+  RankGroup& G = *h->grp;
+  if (h->cfg.rank == 0) G.ctl_stop[iteration & 1].store(*code, std::memory_order_release);
+  if (G.barrier()) return fail(h, MIBA_ERR_RCCL, "a rank of the group left the solve (see its error)");
+  *code = G.ctl_stop[iteration & 1].load(std::memory_order_acquire);
+  return MIBA_OK;
+}
 
 // ---- building blocks -----------------------------------------------------------------------
 int launch_cam_tables(miba_handle h, const double* cam, bool candidate = false) {
@@ -723,7 +791,7 @@ constexpr int64_t kDensePlanMax = (int64_t)1 << 28;
 int dense_plan(miba_handle h) {
   h->dense_planned = false;
   if (const char* e = getenv("MIBA_DENSE_PLAN")) if (atoi(e) == 0) return MIBA_OK;
-  const Plan& P = h->plan;
+  const Plan& P = h->plan_ref();
   const int32_t nc = h->n_cam;
   if (nc > 4096) return MIBA_OK;
   const size_t nkey = (size_t)nc * (nc + 1) / 2;
@@ -935,7 +1003,13 @@ int read_scalars(miba_handle h) {
   HIPCHK(h, hipMemcpyAsync(h->h_scal, h->d_sum, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipMemcpyAsync(h->h_scal + S_COUNT, h->d_max, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
-  return sync_stream(h);
+  const bool peer = h->grp && h->grp->mode == kCommPeer && h->grp->n > 1;
+  uint32_t* tmo = (uint32_t*)(h->h_scal + 2 * S_COUNT);   // last slot of the pinned scalar block
+  if (peer) HIPCHK(h, hipMemcpyAsync(tmo, &h->grp->psig[h->cfg.rank]->timeout, sizeof(uint32_t), hipMemcpyDeviceToHost, h->st));
+  int rc = sync_stream(h);
+  if (rc) return rc;
+  if (peer && *tmo) return fail(h, MIBA_ERR_RCCL, "peer all-reduce timed out: a rank of the group never arrived");
+  return MIBA_OK;
 }
 
 // make d_J the scaled Jacobian of the current state (computing the Jacobi scale on first use)
@@ -1032,7 +1106,7 @@ int miba_comm_unique_id(void* out128) {
   return MIBA_OK;
 }
 
-int miba_create(const miba_config* cfg, miba_handle* out) {
+static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out) {
   if (!cfg || !out) return fail(nullptr, MIBA_ERR_INVALID, "null argument");
   if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size)
     return fail(nullptr, MIBA_ERR_INVALID, "bad rank/world_size %d/%d", cfg->rank, cfg->world_size);
@@ -1050,8 +1124,10 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
   h->cfg.comm_unique_id = nullptr;
   h->device = dev;
   hipError_t e = hipSetDevice(dev);
-  if (e == hipSuccess) e = hipStreamCreate(&h->st);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_scal, 2 * S_COUNT * sizeof(double));
+  // non-blocking: no implicit synchronisation with the null stream (every copy below is stream-ordered or follows an
+  // explicit sync; with several ranks on one device a null-stream copy of one rank must not wait for a peer's kernels)
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_scal, (2 * S_COUNT + 1) * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl));
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming);
   if (e == hipSuccess) e = static_scratch_for(dev, &h->static_scratch);   // device `dev` is current here
@@ -1068,29 +1144,7 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
     return rc;
   }
   const char* force = getenv("MIBA_FORCE_RCCL");
-  // MIBA_TEST_NO_COMM=1 (tests only): a rank of a multi-rank world without a communicator, so that its
-  // un-reduced partial sums can be inspected on a single GPU; solves are meaningless in this mode
-  const char* nocomm = getenv("MIBA_TEST_NO_COMM");
-  const bool no_comm = nocomm && nocomm[0] == '1';
-  const char* shm_name = getenv("MIBA_TEST_SHM_COMM");
-  if (!no_comm && cfg->world_size > 1 && shm_name && shm_name[0]) {
-    ShmComm* C = new ShmComm();
-    C->name = std::string("/") + shm_name;
-    C->world = cfg->world_size;
-    C->rank = cfg->rank;
-    C->bytes = sizeof(ShmHeader) + (size_t)cfg->world_size * kShmChunk * sizeof(double);
-    const int fd = shm_open(C->name.c_str(), O_CREAT | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)C->bytes) != 0) {
-      if (fd >= 0) close(fd);
-      delete C; delete h;
-      return fail(nullptr, MIBA_ERR_INVALID, "MIBA_TEST_SHM_COMM: cannot create shared memory %s", shm_name);
-    }
-    C->base = mmap(nullptr, C->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (C->base == MAP_FAILED) { delete C; delete h; return fail(nullptr, MIBA_ERR_NOMEM, "MIBA_TEST_SHM_COMM: mmap failed"); }
-    h->shm = C;
-    C->barrier();   // every rank has mapped the (zero-filled) segment
-  } else if (!no_comm && (cfg->world_size > 1 || (force && force[0] == '1'))) {
+  if (make_comm && (cfg->world_size > 1 || (force && force[0] == '1'))) {
     ncclUniqueId id;
     if (cfg->comm_unique_id) memcpy(&id, cfg->comm_unique_id, sizeof(id));
     else if (cfg->world_size == 1) {
@@ -1107,8 +1161,122 @@ int miba_create(const miba_config* cfg, miba_handle* out) {
   return MIBA_OK;
 }
 
+int miba_create(const miba_config* cfg, miba_handle* out) { return create_impl(cfg, true, out); }
+
+namespace {
+// rank handle of a group: device state only, the communicator comes from the group
+int create_rank(int device, int rank, int world, int log_level, miba_handle* out) {
+  miba_config c{};
+  c.device_id = device; c.rank = 0; c.world_size = 1; c.log_level = log_level; c.comm_unique_id = nullptr;
+  int rc = create_impl(&c, false, out);   // the group makes the communicators
+  if (rc) return rc;
+  (*out)->cfg.rank = rank;
+  (*out)->cfg.world_size = world;
+  return MIBA_OK;
+}
+
+void destroy_group(RankGroup* G) {
+  if (!G) return;
+  for (size_t r = 0; r < G->sub.size(); ++r) {
+    miba_handle s = G->sub[r];
+    if (!s) continue;
+    (void)hipSetDevice(s->device);
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    if (r < G->hbuf.size() && G->hbuf[r]) (void)hipHostFree(G->hbuf[r]);
+    if (G->n + r < G->hbuf.size() && G->hbuf[G->n + r]) (void)hipHostFree(G->hbuf[G->n + r]);
+    if (r < G->pstage.size() && G->pstage[r]) (void)hipFree(G->pstage[r]);
+    if (r < G->psig.size() && G->psig[r]) (void)hipFree(G->psig[r]);
+    s->grp = nullptr;
+    miba_destroy(s);   // also destroys the rank's RCCL communicator
+  }
+  delete G;
+}
+}  // namespace
+
+int miba_create_multi(const int32_t* device_ids, int32_t n_devices, int32_t log_level, miba_handle* out) {
+  if (!out || n_devices < 1 || n_devices > kMaxRanks) return fail(nullptr, MIBA_ERR_INVALID, "n_devices must be 1..%d", kMaxRanks);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MIBA_ERR_NO_DEVICE, "no HIP device available (libmiba has no CPU fallback)");
+  std::vector<int> dev(n_devices);
+  bool repeated = false;
+  for (int r = 0; r < n_devices; ++r) {
+    dev[r] = device_ids ? device_ids[r] : r;
+    if (dev[r] < 0 || dev[r] >= ndev) return fail(nullptr, MIBA_ERR_INVALID, "device %d out of range (%d devices)", dev[r], ndev);
+    for (int q = 0; q < r; ++q) repeated |= dev[q] == dev[r];
+  }
+  miba_handle g = new (std::nothrow) miba_handle_s();
+  RankGroup* G = new (std::nothrow) RankGroup();
+  if (!g || !G) { delete g; delete G; return fail(nullptr, MIBA_ERR_NOMEM, "out of host memory"); }
+  g->owned = G;
+  g->cfg.device_id = dev[0]; g->cfg.rank = 0; g->cfg.world_size = n_devices; g->cfg.log_level = log_level;
+  g->device = dev[0];
+  G->n = n_devices;
+  G->ctl_stop[0].store(0); G->ctl_stop[1].store(0);
+  G->sub.assign(n_devices, nullptr);
+  // transport: RCCL for distinct devices, the host-staged one when a device repeats (RCCL refuses that);
+  // MIBA_ALLREDUCE=peer|host|rccl overrides
+  G->mode = repeated ? kCommHost : kCommRccl;
+  if (const char* e = getenv("MIBA_ALLREDUCE")) {
+    if (!strcmp(e, "peer")) G->mode = kCommPeer;
+    else if (!strcmp(e, "host")) G->mode = kCommHost;
+    else if (!strcmp(e, "rccl")) G->mode = kCommRccl;
+    else { destroy_group(G); delete g; return fail(nullptr, MIBA_ERR_INVALID, "MIBA_ALLREDUCE must be rccl, peer or host"); }
+  }
+  if (G->mode == kCommRccl && repeated) { destroy_group(G); delete g; return fail(nullptr, MIBA_ERR_INVALID, "RCCL cannot put two ranks on one device"); }
+  int rc = MIBA_OK;
+  for (int r = 0; r < n_devices && rc == MIBA_OK; ++r) {
+    rc = create_rank(dev[r], r, n_devices, log_level, &G->sub[r]);
+    if (rc == MIBA_OK) G->sub[r]->grp = G;
+  }
+  if (rc == MIBA_OK && n_devices > 1) {
+    if (G->mode == kCommRccl) {
+      std::vector<ncclComm_t> comms(n_devices);
+      const ncclResult_t nr = ncclCommInitAll(comms.data(), n_devices, dev.data());
+      if (nr != ncclSuccess) rc = fail(nullptr, MIBA_ERR_RCCL, "ncclCommInitAll failed: %s", ncclGetErrorString(nr));
+      else for (int r = 0; r < n_devices; ++r) G->sub[r]->comm = comms[r];
+    } else if (G->mode == kCommHost) {
+      G->hbuf.assign(2 * (size_t)n_devices, nullptr);
+      for (int r = 0; r < 2 * n_devices && rc == MIBA_OK; ++r)
+        if (hipHostMalloc((void**)&G->hbuf[r], kPeerChunk * sizeof(double)) != hipSuccess) rc = fail(nullptr, MIBA_ERR_NOMEM, "pinned staging allocation failed");
+    } else {
+      G->pstage.assign(n_devices, nullptr);
+      G->psig.assign(n_devices, nullptr);
+      for (int r = 0; r < n_devices && rc == MIBA_OK; ++r) {
+        hipError_t e = hipSetDevice(dev[r]);
+        for (int q = 0; q < n_devices && e == hipSuccess; ++q)
+          if (dev[q] != dev[r]) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(dev[q], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+            (void)hipGetLastError();
+          }
+        // fine-grained device memory: coherent for the peers' system-scope loads and stores
+        if (e == hipSuccess) e = hipExtMallocWithFlags((void**)&G->pstage[r], 2 * kPeerChunk * sizeof(double), hipDeviceMallocFinegrained);
+        if (e == hipSuccess) e = hipExtMallocWithFlags((void**)&G->psig[r], sizeof(PeerSignals), hipDeviceMallocFinegrained);
+        if (e == hipSuccess) e = hipMemset(G->psig[r], 0, sizeof(PeerSignals));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = fail(nullptr, MIBA_ERR_HIP, "peer transport setup failed on device %d: %s", dev[r], hipGetErrorString(e));
+      }
+    }
+  }
+  if (rc != MIBA_OK) {
+    const std::string msg = g_last_error;
+    destroy_group(G);
+    delete g;
+    g_last_error = msg;
+    return rc;
+  }
+  *out = g;
+  return MIBA_OK;
+}
+
 int miba_destroy(miba_handle h) {
   if (!h) return MIBA_OK;
+  if (h->owned) {
+    destroy_group(h->owned);
+    delete h;
+    return MIBA_OK;
+  }
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
   free_problem(h);
@@ -1117,12 +1285,6 @@ int miba_destroy(miba_handle h) {
   for (auto& e : h->ev_busy) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (h->ev_poll) (void)hipEventDestroy(h->ev_poll);
   if (h->comm) (void)ncclCommDestroy(h->comm);
-  if (h->shm) {
-    h->shm->barrier();   // nobody is inside a reduction any more
-    munmap(h->shm->base, h->shm->bytes);
-    if (h->shm->rank == 0) shm_unlink(h->shm->name.c_str());
-    delete h->shm;
-  }
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -1167,7 +1329,7 @@ int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* ow
   return MIBA_OK;
 }
 
-int miba_set_problem(miba_handle h, const miba_problem* p) {
+static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_ptr<Plan> shared) {
   if (!h || !p) return fail(h, MIBA_ERR_INVALID, "null argument");
   if (!p->R || !p->T || !p->K || !p->X || (p->n_obs > 0 && (!p->obs_cam || !p->obs_pt || !p->obs_xy)))
     return fail(h, MIBA_ERR_INVALID, "null problem array");
@@ -1180,9 +1342,11 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     h->k2_onepass = op && op[0] == '1';
   }
   const char* po = getenv("MIBA_POINT_ORDER");
-  Plan& P = h->plan;
-  int rc = build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->cfg.world_size,
-                      po ? atoi(po) : 1);
+  // the ranks of a single-process group share one plan (built once by the group), a stand-alone rank builds its own
+  if (shared) h->plan_sp = shared; else h->plan_sp = std::make_shared<Plan>();
+  Plan& P = h->plan_ref();
+  int rc = shared ? 0 : build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->cfg.world_size,
+                                   po ? atoi(po) : 1);
   if (rc) return fail(h, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", rc);
   PlanLap lap;
   h->n_cam = p->n_cam;
@@ -1363,14 +1527,34 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
   HIPCHK(h, hipMemsetAsync(h->d_part_pcg, 0, 5 * (size_t)kPcgMaxBlocks * sizeof(double), h->st));
   HIPCHK(h, hipStreamSynchronize(h->st));
   // the big host-side index arrays are not needed any more, except slot_orig / pt_orig (evaluate, get_state)
-  std::vector<int32_t>().swap(P.idx);
-  std::vector<int32_t>().swap(P.ocam);
+  if (!shared) {
+    std::vector<int32_t>().swap(P.idx);
+    std::vector<int32_t>().swap(P.ocam);
+  }
   h->has_problem = true;
   memset(&h->kt, 0, sizeof(h->kt));
   return miba_set_state(h, p->R, p->T, p->K, p->X);
 }
 
+int miba_set_problem(miba_handle h, const miba_problem* p) {
+  if (h && h->owned) {
+    if (!p) return fail(h, MIBA_ERR_INVALID, "null argument");
+    // one plan for all ranks, built once
+    auto P = std::make_shared<Plan>();
+    const char* po = getenv("MIBA_POINT_ORDER");
+    const int prc = build_plan(*P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->owned->n, po ? atoi(po) : 1);
+    if (prc) return fail(h, prc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", prc);
+    const int rc = group_run(h, [&](miba_handle s, int) { return set_problem_impl(s, p, P); });
+    std::vector<int32_t>().swap(P->idx);
+    std::vector<int32_t>().swap(P->ocam);
+    h->has_problem = rc == MIBA_OK;
+    return rc;
+  }
+  return set_problem_impl(h, p, nullptr);
+}
+
 int miba_set_state(miba_handle h, const double* R, const double* T, const double* K, const double* X) {
+  if (h && h->owned) return group_run(h, [&](miba_handle s, int) { return miba_set_state(s, R, T, K, X); });
   if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
   if (!R || !T || !K || !X) return fail(h, MIBA_ERR_INVALID, "null state array");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1392,7 +1576,7 @@ int miba_set_state(miba_handle h, const double* R, const double* T, const double
   }
   std::vector<double> pts(3 * (size_t)(h->n_pt ? h->n_pt : 1));
   for (int32_t q = 0; q < h->n_pt; ++q) {
-    const size_t o = (size_t)h->plan.pt_orig[h->pt_base + q];
+    const size_t o = (size_t)h->plan_ref().pt_orig[h->pt_base + q];
     pts[3 * (size_t)q] = X[3 * o]; pts[3 * (size_t)q + 1] = X[3 * o + 1]; pts[3 * (size_t)q + 2] = X[3 * o + 2];
   }
   int rc = upload(h, h->d_cam, cam.data(), cam.size());
@@ -1405,6 +1589,7 @@ int miba_set_state(miba_handle h, const double* R, const double* T, const double
 }
 
 int miba_set_constant_blocks(miba_handle h, const uint8_t* cam_const) {
+  if (h && h->owned) return group_run(h, [&](miba_handle s, int) { return miba_set_constant_blocks(s, cam_const); });
   if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<double> m(9 * (size_t)h->n_cam, 1.0);
@@ -1420,20 +1605,30 @@ int miba_set_constant_blocks(miba_handle h, const uint8_t* cam_const) {
 }
 
 int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
+  if (h && h->owned) {
+    // On the calling thread, rank after rank (it may be called from inside an iteration callback, while the rank threads
+    // wait for the callback's verdict): cameras from rank 0, every rank's own points.
+    for (int r = 0; r < h->owned->n; ++r) {
+      miba_handle s = h->owned->sub[r];
+      const int rc = miba_get_state(s, r ? nullptr : R, r ? nullptr : T, r ? nullptr : K, X);
+      if (rc) { h->err = s->err; return rc; }
+    }
+    return MIBA_OK;
+  }
   if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<double> cam(9 * (size_t)h->n_cam);
   HIPCHK(h, hipMemcpyAsync(cam.data(), h->d_cam, cam.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipStreamSynchronize(h->st));
   for (int c = 0; c < h->n_cam; ++c) {
-    if (!h->plan.cam_active[c]) continue;   // blocks that are not in the problem stay untouched
+    if (!h->plan_ref().cam_active[c]) continue;   // blocks that are not in the problem stay untouched
     const double* o = cam.data() + 9 * (size_t)c;
     if (R) { R[3 * c] = o[0]; R[3 * c + 1] = o[1]; R[3 * c + 2] = o[2]; }
     if (T) { T[3 * c] = o[3]; T[3 * c + 1] = o[4]; T[3 * c + 2] = o[5]; }
     if (K) { K[6 * c] = o[6]; K[6 * c + 1] = o[6]; K[6 * c + 4] = o[7]; K[6 * c + 5] = o[8]; }   // ox, oy are not the solver's
   }
   if (!X) return MIBA_OK;
-  const size_t n_act = h->plan.pt_orig.size();
+  const size_t n_act = h->plan_ref().pt_orig.size();
   // pinned staging buffer, kept: per-iteration state pulls (update_state_every_iteration) copy at full PCIe rate
   const size_t need = 3 * (n_act ? n_act : 1);
   if (h->h_stage_n < need) {
@@ -1443,8 +1638,9 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
     h->h_stage_n = need;
   }
   double* pts = h->h_stage;
-  if (multi_rank(h) && h->cfg.world_size > 1) {
-    // every rank contributes its own points to a zero-filled buffer; sum = gather
+  if (multi_rank(h) && h->cfg.world_size > 1 && !h->grp) {
+    // one process per rank: every rank contributes its own points to a zero-filled buffer; sum = gather
+    // (the ranks of a single-process group write their own points straight into the caller's array instead)
     double* d_all = nullptr;
     HIPCHK(h, hipMalloc((void**)&d_all, 3 * (n_act ? n_act : 1) * sizeof(double)));
     hipError_t e = hipMemsetAsync(d_all, 0, 3 * n_act * sizeof(double), h->st);
@@ -1457,7 +1653,7 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
     (void)hipFree(d_all);
     if (rcg != MIBA_OK) return rcg;
     if (e != hipSuccess) return fail(h, MIBA_ERR_HIP, "point download failed: %s", hipGetErrorString(e));
-    const int32_t* po = h->plan.pt_orig.data();
+    const int32_t* po = h->plan_ref().pt_orig.data();
     plan_parallel_for((int64_t)n_act, [&](int64_t a, int64_t b) {
       for (int64_t s = a; s < b; ++s) {
         const size_t o = (size_t)po[s];
@@ -1469,7 +1665,7 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
       HIPCHK(h, hipMemcpyAsync(pts, h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToHost, h->st));
       HIPCHK(h, hipStreamSynchronize(h->st));
     }
-    const int32_t* po = h->plan.pt_orig.data() + h->pt_base;
+    const int32_t* po = h->plan_ref().pt_orig.data() + h->pt_base;
     plan_parallel_for((int64_t)h->n_pt, [&](int64_t a, int64_t b) {
       for (int64_t q = a; q < b; ++q) {
         const size_t o = (size_t)po[q];
@@ -1482,6 +1678,23 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
 
 int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_cam, double* jac_pt, double* grad_cam,
                   double* grad_pt) {
+  if (h && h->owned) {
+    RankGroup& G = *h->owned;
+    if (!G.sub[0]->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
+    const Plan& P = G.sub[0]->plan_ref();
+    if (residuals) memset(residuals, 0, sizeof(double) * 2 * (size_t)P.n_obs_in);
+    if (jac_cam) memset(jac_cam, 0, sizeof(double) * 18 * (size_t)P.n_obs_in);
+    if (jac_pt) memset(jac_pt, 0, sizeof(double) * 6 * (size_t)P.n_obs_in);
+    if (grad_pt) memset(grad_pt, 0, sizeof(double) * 3 * (size_t)P.n_pt_in);
+    // every rank fills its own observations and points; the replicated outputs (cost, camera gradient) are rank 0's,
+    // the other ranks write theirs (the same numbers) into scratch
+    std::vector<std::vector<double>> gc(G.n);
+    std::vector<double> c(G.n, 0.0);
+    if (grad_cam) for (int r = 1; r < G.n; ++r) gc[r].resize(9 * (size_t)P.n_cam);
+    return group_run(h, [&](miba_handle s, int r) {
+      return miba_evaluate(s, r ? &c[r] : cost, residuals, jac_cam, jac_pt, grad_cam ? (r ? gc[r].data() : grad_cam) : nullptr, grad_pt);
+    });
+  }
   if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
   HIPCHK(h, hipSetDevice(h->device));
   miba_options o;
@@ -1502,11 +1715,13 @@ int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_ca
   rc = sync_stream(h);
   if (rc) return rc;
   if (cost) *cost = h->h_scal[S_COST];
-  const Plan& P = h->plan;
+  const Plan& P = h->plan_ref();
   if (residuals || jac_cam || jac_pt) {
-    if (residuals) memset(residuals, 0, sizeof(double) * 2 * (size_t)P.n_obs_in);
-    if (jac_cam) memset(jac_cam, 0, sizeof(double) * 18 * (size_t)P.n_obs_in);
-    if (jac_pt) memset(jac_pt, 0, sizeof(double) * 6 * (size_t)P.n_obs_in);
+    if (!h->grp) {   // (the ranks of a group fill one array that the group has cleared)
+      if (residuals) memset(residuals, 0, sizeof(double) * 2 * (size_t)P.n_obs_in);
+      if (jac_cam) memset(jac_cam, 0, sizeof(double) * 18 * (size_t)P.n_obs_in);
+      if (jac_pt) memset(jac_pt, 0, sizeof(double) * 6 * (size_t)P.n_obs_in);
+    }
     std::vector<double> J((size_t)kJComp * (size_t)(h->n_slots ? h->n_slots : 1));
     if (h->n_slots) {
       HIPCHK(h, hipMemcpyAsync(J.data(), h->d_J, J.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
@@ -1541,7 +1756,7 @@ int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_ca
       for (int c = 0; c < h->n_cam; ++c)
         for (int k = 0; k < 9; ++k) grad_cam[9 * (size_t)c + k] = acc[(size_t)kK2W * c + 54 + k];
     if (grad_pt) {
-      memset(grad_pt, 0, sizeof(double) * 3 * (size_t)P.n_pt_in);
+      if (!h->grp) memset(grad_pt, 0, sizeof(double) * 3 * (size_t)P.n_pt_in);
       for (int32_t q = 0; q < h->n_pt; ++q) {
         const size_t ob = (size_t)P.pt_orig[h->pt_base + q];
         for (int k = 0; k < 3; ++k) grad_pt[3 * ob + k] = gpv[3 * (size_t)q + k];
@@ -1553,6 +1768,22 @@ int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_ca
 
 int miba_linear_step(miba_handle h, const miba_options* opt, double radius, double* y_cam, double* y_pt, double* rhs,
                      const double* probe, double* s_probe, int32_t* n_cg, double* model_cost_change) {
+  if (h && h->owned) {
+    RankGroup& G = *h->owned;
+    if (!G.sub[0]->has_problem) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
+    const Plan& P = G.sub[0]->plan_ref();
+    if (y_pt) memset(y_pt, 0, sizeof(double) * 3 * (size_t)P.n_pt_in);
+    const size_t nc9 = 9 * (size_t)P.n_cam;
+    std::vector<std::vector<double>> tmp(G.n);   // replicated camera-sized outputs of the ranks other than 0
+    for (int r = 1; r < G.n; ++r) tmp[r].resize(3 * nc9);
+    std::vector<int32_t> it(G.n, 0);
+    std::vector<double> mc(G.n, 0.0);
+    return group_run(h, [&](miba_handle s, int r) {
+      double* t = r ? tmp[r].data() : nullptr;
+      return miba_linear_step(s, opt, radius, y_cam ? (r ? t : y_cam) : nullptr, y_pt, rhs ? (r ? t + nc9 : rhs) : nullptr, probe,
+                              s_probe ? (r ? t + 2 * nc9 : s_probe) : nullptr, r ? &it[r] : n_cg, r ? &mc[r] : model_cost_change);
+    });
+  }
   if (!h || !h->has_problem || !opt) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
   if (!(radius > 0.0)) return fail(h, MIBA_ERR_INVALID, "radius must be positive");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1578,11 +1809,11 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
   if (y_cam) HIPCHK(h, hipMemcpy(y_cam, h->d_px, n * sizeof(double), hipMemcpyDeviceToHost));
   if (rhs) HIPCHK(h, hipMemcpy(rhs, h->d_rhs, n * sizeof(double), hipMemcpyDeviceToHost));
   if (y_pt) {
-    memset(y_pt, 0, sizeof(double) * 3 * (size_t)h->plan.n_pt_in);
+    if (!h->grp) memset(y_pt, 0, sizeof(double) * 3 * (size_t)h->plan_ref().n_pt_in);
     std::vector<double> v(3 * (size_t)(h->n_pt ? h->n_pt : 1));
     if (h->n_pt) HIPCHK(h, hipMemcpy(v.data(), h->d_yp, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToHost));
     for (int32_t q = 0; q < h->n_pt; ++q) {
-      const size_t ob = (size_t)h->plan.pt_orig[h->pt_base + q];
+      const size_t ob = (size_t)h->plan_ref().pt_orig[h->pt_base + q];
       for (int k = 0; k < 3; ++k) y_pt[3 * ob + k] = v[3 * (size_t)q + k];
     }
   }
@@ -1599,6 +1830,7 @@ int miba_linear_step(miba_handle h, const miba_options* opt, double radius, doub
 }
 
 int miba_get_reduced_system(miba_handle h, double* S_out) {
+  if (h && h->owned) return group_run(h, [&](miba_handle s, int) { return miba_get_reduced_system(s, S_out); });
   if (!h || !h->has_problem || !S_out) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->jac_valid) return fail(h, MIBA_ERR_INVALID, "call miba_linear_step first (Schur blocks not set up)");
@@ -1610,6 +1842,7 @@ int miba_get_reduced_system(miba_handle h, double* S_out) {
   rc = sync_stream(h);
   if (rc) return rc;
   const size_t N = (size_t)h->dense_N;
+  if (h->grp && h->cfg.rank != 0) return MIBA_OK;   // the all-reduced matrix is the same on every rank: rank 0 hands it out
   HIPCHK(h, hipMemcpy2D(S_out, n * sizeof(double), h->d_S, N * sizeof(double), n * sizeof(double), n, hipMemcpyDeviceToHost));
   for (size_t r = 0; r < n; ++r)
     for (size_t c = r + 1; c < n; ++c) S_out[r * n + c] = S_out[c * n + r];
@@ -1617,6 +1850,11 @@ int miba_get_reduced_system(miba_handle h, double* S_out) {
 }
 
 int miba_dense_spd_solve(miba_handle h, int32_t n, const double* A, const double* b, double* x, int32_t* status) {
+  if (h && h->owned) {   // no collective inside: rank 0's device does it
+    const int rc = miba_dense_spd_solve(h->owned->sub[0], n, A, b, x, status);
+    if (rc) h->err = h->owned->sub[0]->err;
+    return rc;
+  }
   if (!h || n < 1 || !A || !b || !x || !status) return fail(h, MIBA_ERR_INVALID, "bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t N = ((size_t)n + kNB - 1) / kNB * kNB;
@@ -1650,6 +1888,11 @@ int miba_dense_spd_solve(miba_handle h, int32_t n, const double* A, const double
 }
 
 int miba_dense_spd_solve_static(miba_handle h, int32_t n, const double* d_A, const double* d_b, double* d_x, int32_t* d_status) {
+  if (h && h->owned) {   // rank 0's device (the pointers must live there)
+    const int rc = miba_dense_spd_solve_static(h->owned->sub[0], n, d_A, d_b, d_x, d_status);
+    if (rc) h->err = h->owned->sub[0]->err;
+    return rc;
+  }
   if (!h || n < 1 || !d_A || !d_b || !d_x || !d_status) return fail(h, MIBA_ERR_INVALID, "bad argument");
   const size_t N = ((size_t)n + kNB - 1) / kNB * kNB;
   if (N > (size_t)kStaticMaxN)
@@ -1673,6 +1916,10 @@ int miba_dense_spd_solve_static(miba_handle h, int32_t n, const double* d_A, con
 }
 
 int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* avg_ms) {
+  if (h && h->owned) {
+    std::vector<double> ms(h->owned->n, 0.0);
+    return group_run(h, [&](miba_handle s, int r) { return miba_time_matvec(s, probe, reps, r ? &ms[r] : avg_ms); });
+  }
   if (!h || !h->has_problem || !probe || !avg_ms || reps < 1) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->jac_valid) return fail(h, MIBA_ERR_INVALID, "call miba_linear_step first (Jacobian / Schur blocks not set up)");
@@ -1703,6 +1950,12 @@ int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* a
 }
 
 int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback cb, void* user, miba_summary* summary) {
+  if (h && h->owned) {
+    // every rank runs the same LM loop on its own thread; the callback belongs to rank 0 (the caller's thread), which
+    // hands its verdict to the others once per iteration (group_exchange_stop)
+    std::vector<miba_summary> sm(h->owned->n);
+    return group_run(h, [&](miba_handle s, int r) { return miba_solve(s, opt, r ? nullptr : cb, r ? nullptr : user, r ? &sm[r] : summary); });
+  }
   if (!h || !h->has_problem || !opt) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
   HIPCHK(h, hipSetDevice(h->device));
   const miba_options o = *opt;
@@ -1713,8 +1966,8 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
   memset(&S, 0, sizeof(S));
   S.termination_type = MIBA_NO_CONVERGENCE;
   S.num_residual_blocks = (int32_t)std::min<int64_t>(h->n_valid_global, INT32_MAX);
-  S.num_active_cameras = h->plan.n_active_cam;
-  S.num_active_points = (int32_t)h->plan.pt_orig.size();
+  S.num_active_cameras = h->plan_ref().n_active_cam;
+  S.num_active_points = (int32_t)h->plan_ref().pt_orig.size();
   S.exact_linear_solver = dense_wanted(h, &o) ? 1 : 0;
   snprintf(S.message, sizeof(S.message), "Maximum number of iterations reached.");
   int rc = set_loss(h, &o);
@@ -1765,15 +2018,23 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
     it.trust_region_radius = radius;
     h->iters.push_back(it);
     if (o.minimizer_progress_to_stdout && h->cfg.rank == 0) print_progress(it, it.iteration == 0);
+    // verdicts that depend on the caller or on a clock (callback result, time limit): in a single-process group they are
+    // rank 0's, handed to the other ranks here, so that every rank leaves the loop in the same iteration
+    int stop = 0;
     if (cb) {
       const double tc = now_s();
       const int r = cb(&it, user);
       t_callbacks += now_s() - tc;
-      if (r == MIBA_SOLVER_ABORT) { S.termination_type = MIBA_USER_FAILURE; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_ABORT."); user_stop = true; }
-      else if (r == MIBA_SOLVER_TERMINATE_SUCCESSFULLY) { S.termination_type = MIBA_USER_SUCCESS; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_TERMINATE_SUCCESSFULLY."); user_stop = true; }
+      if (r == MIBA_SOLVER_ABORT) stop = 1;
+      else if (r == MIBA_SOLVER_TERMINATE_SUCCESSFULLY) stop = 2;
     }
+    if (!stop && now_s() - t_start - t_callbacks >= o.max_solver_time_in_seconds) stop = 3;
+    rc = group_exchange_stop(h, it.iteration, &stop);
+    if (rc) return rc;
+    if (stop == 1) { S.termination_type = MIBA_USER_FAILURE; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_ABORT."); user_stop = true; }
+    else if (stop == 2) { S.termination_type = MIBA_USER_SUCCESS; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_TERMINATE_SUCCESSFULLY."); user_stop = true; }
     if (user_stop) break;
-    if (now_s() - t_start - t_callbacks >= o.max_solver_time_in_seconds) { snprintf(S.message, sizeof(S.message), "Maximum solver time reached."); break; }
+    if (stop == 3) { snprintf(S.message, sizeof(S.message), "Maximum solver time reached."); break; }
     if (it.iteration >= o.max_num_iterations) break;
     if (it.gradient_max_norm <= o.gradient_tolerance) {
       S.termination_type = MIBA_CONVERGENCE;
@@ -1905,6 +2166,7 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
 
 int miba_get_iterations(miba_handle h, miba_iteration* out, int32_t max, int32_t* n) {
   if (!h) return fail(h, MIBA_ERR_INVALID, "null handle");
+  if (h->owned) return miba_get_iterations(h->owned->sub[0], out, max, n);   // identical on every rank
   if (n) *n = (int32_t)h->iters.size();
   if (out)
     for (int32_t i = 0; i < max && i < (int32_t)h->iters.size(); ++i) out[i] = h->iters[i];
@@ -1913,6 +2175,7 @@ int miba_get_iterations(miba_handle h, miba_iteration* out, int32_t max, int32_t
 
 int miba_get_kernel_times(miba_handle h, miba_kernel_times* out) {
   if (!h || !out) return fail(h, MIBA_ERR_INVALID, "null argument");
+  if (h->owned) return miba_get_kernel_times(h->owned->sub[0], out);   // rank 0's shard
   if (h->st) { (void)hipStreamSynchronize(h->st); drain_events(h); }
   *out = h->kt;
   out->n_slots = h->n_slots;
@@ -1925,6 +2188,7 @@ int miba_get_kernel_times(miba_handle h, miba_kernel_times* out) {
 
 int miba_reset_kernel_times(miba_handle h) {
   if (!h) return fail(h, MIBA_ERR_INVALID, "null handle");
+  if (h->owned) { for (miba_handle s : h->owned->sub) (void)miba_reset_kernel_times(s); return MIBA_OK; }
   if (h->st) { (void)hipStreamSynchronize(h->st); drain_events(h); }
   memset(&h->kt, 0, sizeof(h->kt));
   return MIBA_OK;

@@ -147,12 +147,32 @@ void BundleAdjustment::createProblem() {
     }
 
     if (!problem) {
-        miba_config cfg{};
-        cfg.device_id = -1;
-        cfg.rank = 0;
-        cfg.world_size = 1;
+        // One BundleAdjustment object = one handle, whatever the number of GPUs (SURVEY 8b "Threading"): the reference's
+        // call site (app/main.cpp:30-33) has nowhere to say "8 GPUs", so the count comes from the environment.
+        // BA_NUM_GPUS=N (1..8): devices 0..N-1 of this process, points sharded over them; BA_DEVICES=0,0 names the
+        // ordinals explicitly (a repeated ordinal puts several shards on one GPU).
+        std::vector<int32_t> devs;
+        if (const char *dl = getenv("BA_DEVICES")) {
+            for (const char *q = dl; *q;) {
+                char *endp = nullptr;
+                const long v = strtol(q, &endp, 10);
+                if (endp == q) break;
+                devs.push_back((int32_t) v);
+                q = (*endp == ',') ? endp + 1 : endp;
+            }
+        } else if (const char *ng = getenv("BA_NUM_GPUS")) {
+            for (int i = 0; i < atoi(ng); ++i) devs.push_back(i);
+        }
         miba_handle h = nullptr;
-        check(miba_create(&cfg, &h), nullptr, "miba_create");
+        if (devs.size() > 1) {
+            check(miba_create_multi(devs.data(), (int32_t) devs.size(), 0, &h), nullptr, "miba_create_multi");
+        } else {
+            miba_config cfg{};
+            cfg.device_id = devs.empty() ? -1 : devs[0];
+            cfg.rank = 0;
+            cfg.world_size = 1;
+            check(miba_create(&cfg, &h), nullptr, "miba_create");
+        }
         problem = h;
     }
     miba_problem p{};

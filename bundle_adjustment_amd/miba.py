@@ -23,7 +23,7 @@ K_CAM_REDUCE = 7             # camera-side sum of a product, sampled like K3
 K_COUNT = 8
 
 EXPORTS = [
-    "miba_default_options", "miba_create", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
+    "miba_default_options", "miba_create", "miba_create_multi", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
     "miba_plan_shards", "miba_plan_point_owner", "miba_time_matvec", "miba_set_constant_blocks",
@@ -178,10 +178,20 @@ def plan_point_owner(n_cam, n_pt, obs_cam, obs_pt, obs_xy, world_size):
 
 
 class Solver:
-    """One handle = one GPU (one shard).  Mirrors the miba_* entry points one to one."""
+    """One handle = one GPU (one shard), or with devices=[...] one handle for several GPUs.  Mirrors the miba_* entry
+    points one to one."""
 
-    def __init__(self, device_id=-1, rank=0, world_size=1, unique_id=None, log_level=0):
+    def __init__(self, device_id=-1, rank=0, world_size=1, unique_id=None, log_level=0, devices=None):
+        """devices: list of HIP device ordinals for ONE handle that drives several GPUs from this process
+        (miba_create_multi; a repeated ordinal puts several ranks on one GPU); otherwise one handle = one GPU = one rank"""
         self._h = C.c_void_p()
+        self.n_cam = self.n_pt = self.n_obs = 0
+        if devices is not None:
+            ids = (C.c_int32 * len(devices))(*devices)
+            rc = lib().miba_create_multi(ids, C.c_int32(len(devices)), C.c_int32(log_level), C.byref(self._h))
+            if rc != 0:
+                raise MibaError("miba_create_multi rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
+            return
         self._uid = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
         cfg = Config(device_id, rank, world_size, log_level,
                      C.cast(self._uid, C.c_void_p) if self._uid is not None else None)

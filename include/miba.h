@@ -6,8 +6,9 @@
  * Plain pointers and sizes only; no C++/torch/HIP types.  Every entry point returns an int
  * status (MIBA_OK = 0, < 0 error); miba_last_error() gives the text.  The library copies
  * caller data in at miba_set_problem()/miba_set_state() and out at miba_get_state(); it
- * never keeps caller pointers.  A handle is not thread-safe.  One handle drives ONE GPU;
- * multi-GPU runs use one process (one handle) per GPU, joined by an RCCL communicator.
+ * never keeps caller pointers.  A handle is not thread-safe.  A handle of miba_create drives ONE GPU (multi-GPU: one
+ * process and handle per GPU, joined by an RCCL communicator); a handle of miba_create_multi drives several GPUs from
+ * one process.
  *
  * There is NO CPU fallback: every compute entry point fails with MIBA_ERR_NO_DEVICE when no
  * gfx950 device is usable.
@@ -206,6 +207,14 @@ typedef struct {
 void miba_default_options(miba_options* o);
 
 int miba_create(const miba_config* cfg, miba_handle* out);
+/* One handle that drives n_devices GPUs (1..8) from ONE process: what the reference's single `BundleAdjustment ba{data,
+ * options}` (app/main.cpp:30-33) needs to use a whole node.  Points are sharded over the devices exactly as over the
+ * ranks of a one-process-per-GPU world (same plan, same kernels); every entry point takes the handle and runs one host
+ * thread per device inside, the calling thread among them; callbacks run on the calling thread.  device_ids NULL = devices
+ * 0..n-1.  The all-reduce transport is RCCL (ncclCommInitAll) by default; MIBA_ALLREDUCE=peer selects the library's own
+ * 2-hop kernel over peer-mapped staging buffers, MIBA_ALLREDUCE=host a transport staged through host memory, which is
+ * also the default when a device id repeats (several ranks on one GPU: rehearsals and tests; RCCL refuses that). */
+int miba_create_multi(const int32_t* device_ids, int32_t n_devices, int32_t log_level, miba_handle* out);
 int miba_destroy(miba_handle h);
 /* text of the last error on this handle (h may be NULL: last error of a failed miba_create) */
 const char* miba_last_error(miba_handle h);

@@ -1,88 +1,137 @@
-"""Multi-rank control flow on ONE GPU: WORLD processes, each a rank of libmiba with its own shard of the points,
-their all-reduces staged through the shared-memory TEST transport (MIBA_TEST_SHM_COMM; RCCL refuses two ranks on
-one device).  Every rank must report what the one-rank run reports: the same PCG iteration counts, accept/reject
-decisions, costs (to summation-order rounding) and final state, for the iterative, SCHUR_JACOBI and exact
-solvers and for the iterative solver with a Huber loss.  What this cannot cover is RCCL itself and xGMI; test_rccl_path_single_rank covers the RCCL calls."""
+"""Multi-rank control flow on ONE GPU through the reference-shaped API: one handle of miba_create_multi whose ranks all
+sit on device 0 (a repeated device id), each rank with its own shard of the points.  The group must report what the
+one-rank handle reports: the same PCG iteration counts, accept / reject decisions, costs (to summation-order rounding)
+and final state, for the iterative, SCHUR_JACOBI and exact solvers and for the iterative solver with a Huber loss.
+Transports: the host-staged one (default for repeated devices) and the library's own peer all-reduce kernel
+(MIBA_ALLREDUCE=peer; the product kernel of csrc/miba_comm.hpp, here with every "peer" on the same device).  What this
+cannot cover is RCCL across devices and xGMI; test_rccl_path_single_rank covers the RCCL calls at world size 1."""
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
 
+from bundle_adjustment_amd import miba, synth
+
 pytestmark = pytest.mark.gpu
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-WORKER = os.path.join(HERE, "_multirank_worker.py")
+
+def problem(kind):
+    if kind == "medium":
+        pr = synth.make_problem(40, 3000, 14000, seed=11, shuffle_obs=True)
+        cams0, pts0 = synth.perturb(pr, 0.01, 0.1, seed=12)
+        return cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"]
+    # "giant": ordinary points plus one point seen by more cameras than a wavelet holds (giant-tile kernels)
+    rng = np.random.default_rng(3)
+    pr = synth.make_problem(150, 400, 2500, seed=31)
+    cams = pr["cams"]
+    pts = np.concatenate([pr["pts"], np.array([[0.2, -0.1, 0.3]])])
+    cs = rng.choice(150, size=140, replace=False).astype(np.int32)
+    ps = np.full(140, 400, dtype=np.int32)
+    xy, z = synth.project(cams, pts, cs, ps)
+    ok = z < 0
+    oc = np.concatenate([pr["obs_cam"], cs[ok]]); op = np.concatenate([pr["obs_pt"], ps[ok]])
+    oxy = np.concatenate([pr["obs_xy"], xy[ok] + rng.normal(0, 0.5, xy[ok].shape)])
+    cams0 = cams.copy(); cams0[:, 0:6] += rng.normal(0, 0.003, (150, 6))
+    pts0 = pts + rng.normal(0, 0.05, pts.shape)
+    return cams0, pts0, oc, op, oxy
 
 
-def launch(world, tmp_path, kind="medium", extra_env=None):
-    name = "miba_test_%d_%d_%s" % (os.getpid(), world, kind)
-    env = dict(os.environ, MIBA_TEST_SHM_COMM=name, **(extra_env or {}))
-    env.pop("MIBA_TEST_NO_COMM", None)
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(tmp_path / ("w%d_r%d.npz" % (world, r))), kind],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = []
+def run(world, kind, env=None):
+    """the whole sequence of entry points on a handle of `world` ranks (world 1: a plain one-GPU handle)"""
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
     try:
-        for p in procs:
-            o, _ = p.communicate(timeout=150)
-            outs.append(o)
+        cams0, pts0, oc, op, oxy = problem(kind)
+        s = miba.Solver(device_id=0) if world == 1 else miba.Solver(devices=[0] * world)
+        s.set_problem(cams0, pts0, oc, op, oxy)
+        out = {}
+        ev = s.evaluate(jac=True, grad=True)
+        out["eval_cost"], out["grad_cam"], out["grad_pt"], out["r"], out["Jc"] = ev["cost"], ev["grad_cam"], ev["grad_pt"], ev["r"], ev["Jc"]
+        probe = np.random.default_rng(5).normal(size=(cams0.shape[0], 9))
+        ls = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR), probe=probe)
+        out["Sv"], out["y_cam"], out["y_pt"], out["rhs"] = ls["Sv"], ls["y_cam"], ls["y_pt"], ls["rhs"]
+        out["n_cg"], out["mcc"] = ls["n_cg"], ls["model_cost_change"]
+        kw = dict(max_num_iterations=6, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+        for name, o in (("it", miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, **kw)),
+                        ("sj", miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, preconditioner_type=miba.PRECOND_SCHUR_JACOBI, **kw)),
+                        ("ex", miba.default_options(linear_solver_type=miba.DENSE_SCHUR, **kw)),
+                        ("hu", miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, loss_type=miba.LOSS_HUBER, loss_scale=1.0, **kw))):
+            s.set_state(cams0, pts0)
+            seen = []
+            its, summ = s.solve(o, callback=lambda it: seen.append(it.iteration) or 0)
+            assert seen == [r["iteration"] for r in its]   # the callback runs once per record, on the calling thread
+            cams, pts = s.get_state(cams0, pts0)
+            out[name + "_cost"] = np.array([r["cost"] for r in its])
+            out[name + "_ls"] = np.array([r["linear_solver_iterations"] for r in its])
+            out[name + "_ok"] = np.array([r["step_is_successful"] for r in its])
+            out[name + "_final"] = summ["final_cost"]
+            out[name + "_cams"], out[name + "_pts"] = cams, pts
+        s.close()
+        return out
     finally:
-        for p in procs:           # a rank that died leaves the others spinning in a barrier: end them by PID
-            if p.poll() is None:
-                p.kill()
-        try:
-            os.unlink("/dev/shm/" + name)
-        except OSError:
-            pass
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d of %d failed:\n%s" % (r, world, outs[r][-3000:])
-    return [dict(np.load(str(tmp_path / ("w%d_r%d.npz" % (world, r))))) for r in range(world)]
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.fixture(scope="module")
-def single(tmp_path_factory):
-    return launch(1, tmp_path_factory.mktemp("w1"))[0]
+def single():
+    return run(1, "medium")
 
 
 @pytest.fixture(scope="module")
-def single_giant(tmp_path_factory):
-    return launch(1, tmp_path_factory.mktemp("w1g"), "giant", {"MIBA_TILE_CHUNKS": "1"})[0]
+def single_giant():
+    return run(1, "giant", {"MIBA_TILE_CHUNKS": "1"})
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_ranks_agree_with_single_rank(single, world, tmp_path):
-    check(launch(world, tmp_path), single, world)
+def test_group_agrees_with_single_rank(single, world):
+    check(run(world, "medium"), single)
 
 
-def test_ranks_agree_with_single_rank_empty_shards(single, tmp_path):
+def test_group_agrees_with_single_rank_empty_shards(single):
     """Eight ranks for a problem of seven default-size tiles: at least one rank owns nothing and still has to take
     part in every reduction with zeros."""
-    ranks = launch(8, tmp_path, "medium", {"MIBA_TILE_CHUNKS": "8"})
-    assert any(np.abs(o["y_pt"]).sum() == 0.0 for o in ranks)
-    check(ranks, single, 8)
+    pl = miba.plan_shards(40, 3000, *problem("medium")[2:5], 8)
+    assert min(pl["tiles_per_rank"]) == 0
+    check(run(8, "medium", {"MIBA_TILE_CHUNKS": "8"}), single)
 
 
-def test_ranks_agree_with_single_rank_giant_points(single_giant, tmp_path):
+def test_group_agrees_with_single_rank_giant_points(single_giant):
     """One-chunk tiles (so that four ranks all own tiles) and a point with more than 64 observations."""
-    check(launch(4, tmp_path, "giant", {"MIBA_TILE_CHUNKS": "1"}), single_giant, 4)
+    check(run(4, "giant", {"MIBA_TILE_CHUNKS": "1"}), single_giant)
 
 
-def check(ranks, ref, world):
-    for r, out in enumerate(ranks):
-        # every rank holds the same replicated results, bit for bit (sums combined in rank order everywhere)
-        for k in out:
-            if k != "y_pt":   # the point step is handed back by the rank that owns the point (zeros elsewhere)
-                assert np.array_equal(out[k], ranks[0][k]), (world, r, k)
-    owners = sum((np.abs(o["y_pt"]).sum(1) > 0).astype(int) for o in ranks)
-    assert owners.max() == 1   # shards are disjoint
-    out = dict(ranks[0])
-    out["y_pt"] = sum(o["y_pt"] for o in ranks)
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_allreduce_kernel(single, world):
+    """the library's own 2-hop all-reduce kernel (MIBA_ALLREDUCE=peer) under the same expectations.  The rank kernels wait
+    for each other inside the launch, so on ONE device they must be resident together: at most three ranks here (a process
+    has four hardware queues, GPU_MAX_HW_QUEUES, one of them the null stream's; with four ranks two rank streams share a
+    queue and the kernel's bounded spin reports MIBA_ERR_RCCL instead of hanging).  On a node every rank has its own device."""
+    check(run(world, "medium", {"MIBA_ALLREDUCE": "peer"}), single)
+
+
+def test_callback_verdict_reaches_every_rank():
+    """SOLVER_TERMINATE_SUCCESSFULLY from the callback (rank 0, calling thread) stops all ranks in the same iteration"""
+    cams0, pts0, oc, op, oxy = problem("medium")
+    s = miba.Solver(devices=[0, 0, 0])
+    s.set_problem(cams0, pts0, oc, op, oxy)
+    its, summ = s.solve(miba.default_options(max_num_iterations=10), callback=lambda it: 2 if it.iteration == 2 else 0)
+    s.close()
+    assert summ["termination_type"] == miba.USER_SUCCESS and its[-1]["iteration"] == 2
+
+
+def check(out, ref):
     rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
     assert rel(out["rhs"], ref["rhs"]) <= 1e-11 and rel(out["Sv"], ref["Sv"]) <= 1e-11
     assert int(out["n_cg"]) == int(ref["n_cg"]) and rel(out["y_cam"], ref["y_cam"]) <= 1e-8 and rel(out["y_pt"], ref["y_pt"]) <= 1e-8
     assert abs(out["mcc"] - ref["mcc"]) <= 1e-10 * abs(ref["mcc"])
     assert abs(out["eval_cost"] - ref["eval_cost"]) <= 1e-12 * ref["eval_cost"] and rel(out["grad_cam"], ref["grad_cam"]) <= 1e-10
+    # per-observation and per-point outputs are filled by the rank that owns them: together they are the one-rank arrays
+    assert np.array_equal(out["r"], ref["r"]) and np.array_equal(out["Jc"], ref["Jc"])
+    assert rel(out["grad_pt"], ref["grad_pt"]) <= 1e-12
     for name in ("it", "sj", "ex", "hu"):   # iterative, SCHUR_JACOBI, exact, iterative with a Huber loss
         # iterations are compared while the one-rank run still makes progress: beyond that, accept / reject is
         # decided by rounding noise (same rule as test_lm_trajectory_matches_oracle)

@@ -342,48 +342,3 @@ def test_constant_blocks_match_golden_and_oracle(oracle, name):
     for a, b in zip(its2, oits):
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
         assert a["linear_solver_iterations"] == b["linear_solver_iterations"]
-
-
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_shard_partials_add_up(medium, world):
-    """Multi-GPU sharding on one GPU: every rank of a `world`-rank plan is run without a communicator
-    (MIBA_TEST_NO_COMM=1), so its all-reduces are no-ops and it returns its un-reduced partial sums.  The partial
-    costs, right-hand sides, S v products and residual/Jacobian rows of all ranks must add up to the one-rank
-    results: exactly what RCCL's sum produces on a real node."""
-    pr, cams0, pts0 = medium
-    probe = np.random.default_rng(17).normal(size=(pr["n_cam"], 9))
-    opt = miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, jacobi_scaling=0, max_linear_solver_iterations=1)
-    # radius 1e11: the LM diagonal D^2 = clamp(diag J'J) / radius, which a rank without a communicator forms from
-    # its partial J'J, is a 1e-11 relative perturbation of S v (a much larger radius makes the partial camera
-    # blocks numerically singular)
-    s = make_solver(pr, cams0, pts0)
-    full = s.linear_step(1e11, opt, probe=probe)
-    fev = s.evaluate(jac=True, grad=False)
-    s.close()
-    old = os.environ.get("MIBA_TEST_NO_COMM")
-    os.environ["MIBA_TEST_NO_COMM"] = "1"
-    try:
-        Sv, rhs, cost = np.zeros_like(full["Sv"]), np.zeros_like(full["rhs"]), 0.0
-        r, Jc = np.zeros_like(fev["r"]), np.zeros_like(fev["Jc"])
-        ypt = np.zeros_like(full["y_pt"])
-        for rank in range(world):
-            sr = miba.Solver(device_id=0, rank=rank, world_size=world)
-            sr.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
-            out = sr.linear_step(1e11, opt, probe=probe)
-            ev = sr.evaluate(jac=True, grad=False)
-            sr.close()
-            Sv += out["Sv"]; rhs += out["rhs"]; cost += ev["cost"]
-            assert np.all((r == 0) | (ev["r"] == 0))       # an observation lives on exactly one rank
-            r += ev["r"]; Jc += ev["Jc"]
-            assert np.all((ypt == 0) | (out["y_pt"] == 0))  # so does a point
-            ypt += out["y_pt"]
-    finally:
-        if old is None:
-            os.environ.pop("MIBA_TEST_NO_COMM", None)
-        else:
-            os.environ["MIBA_TEST_NO_COMM"] = old
-    assert abs(cost - fev["cost"]) <= 1e-12 * fev["cost"]
-    assert np.array_equal(r, fev["r"]) and np.array_equal(Jc, fev["Jc"])
-    assert rel(rhs, full["rhs"]) <= 1e-12
-    assert rel(Sv, full["Sv"]) <= 1e-9
-    assert np.count_nonzero(np.abs(ypt).sum(1)) == np.count_nonzero(np.abs(full["y_pt"]).sum(1))

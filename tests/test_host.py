@@ -152,3 +152,32 @@ def test_plan_threaded_layout_equals_serial():
     for info, owner in res[1:]:
         assert info == res[0][0]
         assert np.array_equal(owner, res[0][1])
+
+
+def test_multi_device_handle_needs_a_gpu():
+    """miba_create_multi (one handle for several GPUs) is exported and, like every entry point, has no CPU fallback"""
+    import ctypes as C
+    lib = miba.lib()
+    h = C.c_void_p()
+    rc = lib.miba_create_multi(None, C.c_int32(2), C.c_int32(0), C.byref(h))
+    if rc == 0:       # a GPU box: the handle works, then
+        lib.miba_destroy(h)
+        return
+    assert rc == -2 and b"no HIP device" in lib.miba_last_error(None)
+    assert lib.miba_create_multi(None, C.c_int32(9), C.c_int32(0), C.byref(h)) == -1   # 1..8 devices
+
+
+def test_group_plan_is_the_rank_plan():
+    """a handle for N devices builds ONE plan with world size N and hands rank r the tiles [shard_tile[r], shard_tile[r+1]):
+    the same cut N one-rank-per-process handles make (both call build_plan with the same arguments): the shards partition
+    the points, are balanced by observation count, and do not depend on which rank asks"""
+    pr = synth.make_problem(60, 9000, 42000, seed=19, shuffle_obs=True)
+    oc, op, oxy = pr["obs_cam"], pr["obs_pt"], pr["obs_xy"]
+    for world in (2, 4, 8):
+        info = miba.plan_shards(60, 9000, oc, op, oxy, world)
+        owner = miba.plan_point_owner(60, 9000, oc, op, oxy, world)
+        assert sum(info["obs_per_rank"]) == info["n_valid"] == 42000
+        assert set(np.unique(owner)) == set(range(world))
+        counts = np.bincount(owner[op], minlength=world)
+        assert list(counts) == info["obs_per_rank"]
+        assert max(info["obs_per_rank"]) <= 1.25 * min(info["obs_per_rank"]) + 4096
