@@ -76,8 +76,29 @@ int main(int argc, char **argv) {
     if (argc == 3 && std::string(argv[1]) == "--loader") {
         try { return dump_loader(argv[2]); } catch (const std::invalid_argument &e) { printf("invalid_argument %s\n", e.what()); return 3; }
     }
-    double v[14];
+    double v[15];
     static const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (argc == 2 && std::string(argv[1]) == "--model2") {
+        // the reference's live functor: records rot[3] tr[3] fx fy ox oy X[3] obs[2]; prints r, d/drot, d/dtr (2 x 3 each), d/dX
+        BAConstraint::useReferenceModel(true);
+        while (true) {
+            for (int i = 0; i < 15; ++i) if (scanf("%la", &v[i]) != 1) return 0;
+            Eigen::Vector3f obs;
+            obs(0) = (float) v[13]; obs(1) = (float) v[14]; obs(2) = 1.f;
+            std::unique_ptr<ceres::CostFunction> cf(BAConstraint::create(obs, id));
+            double point[3] = {v[10], v[11], v[12]}, rot[3] = {v[0], v[1], v[2]}, tr[3] = {v[3], v[4], v[5]};
+            double K[6] = {v[6], v[7], v[8], v[9], 0.1, -0.2};   // k1, k2 must not matter
+            const double *params[4] = {point, rot, tr, K};
+            double r[2], Jp[6], Jr[6], Jt[6], Jk[12];
+            double *jac[4] = {Jp, Jr, Jt, Jk};
+            if (!cf->Evaluate(params, r, jac)) return 1;
+            printf("%a %a", r[0], r[1]);
+            for (int i = 0; i < 6; ++i) printf(" %a", Jr[i]);
+            for (int i = 0; i < 6; ++i) printf(" %a", Jt[i]);
+            for (int i = 0; i < 6; ++i) printf(" %a", Jp[i]);
+            printf(" %a %a\n", Jk[4] + Jk[5], Jk[10] + Jk[11]);   // d/dk1 + d/dk2: zero
+        }
+    }
     while (true) {
         for (int i = 0; i < 14; ++i) if (scanf("%la", &v[i]) != 1) return 0;
         Eigen::Vector3f obs;

@@ -167,6 +167,8 @@ struct miba_handle_s {
   int32_t n_giant = 0;
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
+  int cam_model = 0;                              // MIBA_MODEL_*: camera model of the problem (miba_problem.camera_model)
+  std::vector<double> principal;                  // model 1: (ox, oy) per camera that the uploaded observations carry
   Loss loss = {kLossNone, 1.0};                   // robust loss of the current solve (options.loss_type / loss_scale)
   double* d_omega = nullptr;                      // [n_slots] loss weights rho' of the current linearisation (loss only)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
@@ -407,7 +409,7 @@ int group_exchange_stop(miba_handle h, int iteration, int* code) {
 // ---- building blocks -----------------------------------------------------------------------
 int launch_cam_tables(miba_handle h, const double* cam, bool candidate = false) {
   hipLaunchKernelGGL(k_cam_tables, dim3(nblk(h->n_cam, 128)), dim3(128), 0, h->st, h->n_cam, cam,
-                     candidate ? h->d_ct_cand : h->d_ct, candidate ? (double*)nullptr : h->d_cm);
+                     candidate ? h->d_ct_cand : h->d_ct, candidate ? (double*)nullptr : h->d_cm, h->cam_model);
   HIPCHK(h, hipGetLastError());
   return MIBA_OK;
 }
@@ -1335,12 +1337,26 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
     return fail(h, MIBA_ERR_INVALID, "null problem array");
   HIPCHK(h, hipSetDevice(h->device));
   free_problem(h);
+  if (p->camera_model != MIBA_MODEL_BAL && p->camera_model != MIBA_MODEL_REFERENCE) return fail(h, MIBA_ERR_INVALID, "unknown camera_model %d", (int)p->camera_model);
+  h->cam_model = p->camera_model;
+  h->principal.clear();
+  if (h->cam_model == MIBA_MODEL_REFERENCE) {
+    // The functor's residual, observed - (f P.xy/P.z + o), is the BAL-shaped residual f (-P.xy/P.z) - (o - observed) of the
+    // camera (R', -R' t, f, 0, 0): the observations are uploaded as o - observed and the per-observation device code is
+    // the BAL code; only the per-camera transforms know the model (k_cam_tables, mf_stage_cam, mf_blocks, k_cam_reduce_mf).
+    h->principal.resize(2 * (size_t)p->n_cam);
+    for (int c = 0; c < p->n_cam; ++c) { h->principal[2 * (size_t)c] = p->K[6 * (size_t)c + 2]; h->principal[2 * (size_t)c + 1] = p->K[6 * (size_t)c + 3]; }
+  }
+  auto obs_x = [&](int64_t o) { return h->cam_model ? h->principal[2 * (size_t)p->obs_cam[o]] - p->obs_xy[2 * o] : p->obs_xy[2 * o]; };
+  auto obs_y = [&](int64_t o) { return h->cam_model ? h->principal[2 * (size_t)p->obs_cam[o] + 1] - p->obs_xy[2 * o + 1] : p->obs_xy[2 * o + 1]; };
   {
     const char* mf = getenv("MIBA_MF");   // matrix-free kernels are the default; MIBA_MF=0 selects the stored-Jacobian path
     h->use_mf = !(mf && mf[0] == '0');
     const char* op = getenv("MIBA_K2_ONEPASS");
     h->k2_onepass = op && op[0] == '1';
   }
+  if (h->cam_model == MIBA_MODEL_REFERENCE && (!h->use_mf || h->k2_onepass))
+    return fail(h, MIBA_ERR_INVALID, "camera model 1 needs the two-pass matrix-free kernels (MIBA_MF=0 or MIBA_K2_ONEPASS=1 is set)");
   const char* po = getenv("MIBA_POINT_ORDER");
   // the ranks of a single-process group share one plan (built once by the group), a stand-alone rank builds its own
   if (shared) h->plan_sp = shared; else h->plan_sp = std::make_shared<Plan>();
@@ -1391,8 +1407,8 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
       const int64_t o = P.slot_orig[h->slot_base + s];
       if (o < 0) continue;
       const size_t chunk = (size_t)(s / kChunk), lane = (size_t)(s % kChunk);
-      oxy[chunk * 2 * kChunk + lane] = p->obs_xy[2 * o];
-      oxy[chunk * 2 * kChunk + kChunk + lane] = p->obs_xy[2 * o + 1];
+      oxy[chunk * 2 * kChunk + lane] = obs_x(o);
+      oxy[chunk * 2 * kChunk + kChunk + lane] = obs_y(o);
     }
   });
   h->n_obs_local = 0;
@@ -1450,7 +1466,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
           const int64_t o = P.slot_orig[h->slot_base + s];
           const int64_t d = cur[P.ocam[h->slot_base + s]]++;
           cmo_pt[d] = (int32_t)q;
-          cmo_xy[d] = make_double2(p->obs_xy[2 * o], p->obs_xy[2 * o + 1]);
+          cmo_xy[d] = make_double2(obs_x(o), obs_y(o));
         }
     });
     for (int c = 0; c < p->n_cam; ++c) {
@@ -1521,6 +1537,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
 #undef UP
   lap("alloc + upload");
   hipLaunchKernelGGL(k_fill, dim3(nblk(9 * nc, 256)), dim3(256), 0, h->st, 9 * nc, 1.0, h->d_cfree);   // all blocks free
+
   HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
   HIPCHK(h, hipMemsetAsync(h->d_max, 0, S_COUNT * sizeof(double), h->st));
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(Ctl), h->st));
@@ -1533,6 +1550,10 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   }
   h->has_problem = true;
   memset(&h->kt, 0, sizeof(h->kt));
+  if (h->cam_model == MIBA_MODEL_REFERENCE) {   // all blocks free, except the intrinsics of the reference's model (src/BundleAdjustment.cpp:77)
+    rc = miba_set_constant_blocks(h, nullptr);
+    if (rc) { free_problem(h); return rc; }
+  }
   return miba_set_state(h, p->R, p->T, p->K, p->X);
 }
 
@@ -1563,6 +1584,12 @@ int miba_set_state(miba_handle h, const double* R, const double* T, const double
   for (int c = 0; c < h->n_cam; ++c) {
     const double* k = K + 6 * (size_t)c;
     const bool f_differs = k[1] != k[0] && !(std::isnan(k[0]) && std::isnan(k[1]));
+    if (h->cam_model == MIBA_MODEL_REFERENCE) {
+      if (f_differs) return fail(h, MIBA_ERR_INVALID, "camera %d: camera model 1 needs fx == fy (got %g, %g)", c, k[0], k[1]);
+      if (k[2] != h->principal[2 * (size_t)c] || k[3] != h->principal[2 * (size_t)c + 1])
+        return fail(h, MIBA_ERR_INVALID, "camera %d: the principal point is part of the uploaded observations; call miba_set_problem to change it", c);
+      continue;
+    }
     if (f_differs || (k[2] != 0.0 && !std::isnan(k[2])) || (k[3] != 0.0 && !std::isnan(k[3])))
       return fail(h, MIBA_ERR_INVALID, "camera %d: intrinsics (fx, fy, ox, oy) = (%g, %g, %g, %g) are not BAL-shaped (fx == fy, ox == oy == 0)",
                   c, k[0], k[1], k[2], k[3]);
@@ -1597,6 +1624,8 @@ int miba_set_constant_blocks(miba_handle h, const uint8_t* cam_const) {
     for (int c = 0; c < h->n_cam; ++c)
       for (int k = 0; k < 9; ++k)
         if (cam_const[3 * (size_t)c + k / 3]) m[9 * (size_t)c + k] = 0.0;
+  if (h->cam_model == MIBA_MODEL_REFERENCE)   // the intrinsics block of the reference's model is always constant
+    for (int c = 0; c < h->n_cam; ++c) m[9 * (size_t)c + 6] = m[9 * (size_t)c + 7] = m[9 * (size_t)c + 8] = 0.0;
   int rc = upload(h, h->d_cfree, m.data(), m.size());
   if (rc) return rc;
   h->scale_valid = false;
@@ -1625,7 +1654,7 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
     const double* o = cam.data() + 9 * (size_t)c;
     if (R) { R[3 * c] = o[0]; R[3 * c + 1] = o[1]; R[3 * c + 2] = o[2]; }
     if (T) { T[3 * c] = o[3]; T[3 * c + 1] = o[4]; T[3 * c + 2] = o[5]; }
-    if (K) { K[6 * c] = o[6]; K[6 * c + 1] = o[6]; K[6 * c + 4] = o[7]; K[6 * c + 5] = o[8]; }   // ox, oy are not the solver's
+    if (K && h->cam_model == MIBA_MODEL_BAL) { K[6 * c] = o[6]; K[6 * c + 1] = o[6]; K[6 * c + 4] = o[7]; K[6 * c + 5] = o[8]; }   // ox, oy are not the solver's
   }
   if (!X) return MIBA_OK;
   const size_t n_act = h->plan_ref().pt_orig.size();

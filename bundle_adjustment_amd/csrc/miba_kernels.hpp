@@ -72,8 +72,11 @@ __device__ __forceinline__ double block_max(double v, double* s4) {
 // K0: per-camera table  [R 0..8 | t 9..11 | f k1 k2 12..14 | - | dR_0 16..24 | dR_1 25..33 | dR_2 34..42]
 // R row-major; dR_j = dR/dw_j (row-major).  Branches as ceres/rotation.h.
 // ---------------------------------------------------------------------------------------------
+// model 1 (the reference's live functor, src/BAConstraint.cpp:15-80: P = R^-1 (X - t), no distortion): the table holds the
+// camera the BAL-shaped per-observation code needs, R~ = R', t~ = -R' t, f, k1 = k2 = 0, dR~_j = (dR_j)', M~ = J_r(-w) = M',
+// and the flag 2 in slot 15 / cm[9]: only the per-camera transforms (staging, reduction, F rows) differ between the models.
 __global__ void k_cam_tables(int n_cam, const double* __restrict__ cam /*[n][9]*/, double* __restrict__ ct,
-                             double* __restrict__ cm /*[n][10] or null*/) {
+                             double* __restrict__ cm /*[n][10] or null*/, int model) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cam) return;
   const double* p = cam + 9 * (size_t)c;
@@ -143,6 +146,31 @@ __global__ void k_cam_tables(int n_cam, const double* __restrict__ cam /*[n][9]*
       m[0] = 1.0; m[1] = 0.0; m[2] = 0.0; m[3] = 0.0; m[4] = 1.0; m[5] = 0.0; m[6] = 0.0; m[7] = 0.0; m[8] = 1.0;
       m[9] = 1.0;
     }
+    if (model == 1) {
+      // M~ = M'; never "small": the small-angle rotation is inverted like any other (R~ = (I + [w]x)' to 1e-16)
+      double t;
+      t = m[1]; m[1] = m[3]; m[3] = t;
+      t = m[2]; m[2] = m[6]; m[6] = t;
+      t = m[5]; m[5] = m[7]; m[7] = t;
+      m[9] = 2.0;
+    }
+  }
+  if (model == 1) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) o[3 * r + q] = R[3 * q + r];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[9 + i] = -(R[i] * p[3] + R[3 + i] * p[4] + R[6 + i] * p[5]);   // -R' t
+    o[12] = p[6]; o[13] = 0.0; o[14] = 0.0;
+    o[15] = 2.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) o[16 + 9 * j + 3 * r + q] = dR[9 * j + 3 * q + r];
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 9; ++i) o[i] = R[i];
@@ -209,25 +237,40 @@ __global__ __launch_bounds__(256) void k_eval(const Tile* __restrict__ tiles, co
       A[0] = -m00 * iz; A[1] = -m01 * iz; A[2] = m00 * q0 + m01 * q1;
       A[3] = -m01 * iz; A[4] = -m11 * iz; A[5] = m01 * q0 + m11 * q1;
       double Fv[18], Ev[6];
-      // rotation columns: A * (dR_j X)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double* D = T + 16 + 9 * j;
-        const double v0 = D[0] * x0 + D[1] * x1 + D[2] * x2;
-        const double v1 = D[3] * x0 + D[4] * x1 + D[5] * x2;
-        const double v2 = D[6] * x0 + D[7] * x1 + D[8] * x2;
-        Fv[j] = A[0] * v0 + A[1] * v1 + A[2] * v2;
-        Fv[9 + j] = A[3] * v0 + A[4] * v1 + A[5] * v2;
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { Fv[3 + j] = A[j]; Fv[12 + j] = A[3 + j]; }
-      Fv[6] = d * px;         Fv[15] = d * py;
-      Fv[7] = f * n * px;     Fv[16] = f * n * py;
-      Fv[8] = f * n * n * px; Fv[17] = f * n * n * py;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         Ev[j] = A[0] * R[j] + A[1] * R[3 + j] + A[2] * R[6 + j];
         Ev[3 + j] = A[3] * R[j] + A[4] * R[3 + j] + A[5] * R[6 + j];
+      }
+      const bool model2 = T[15] == 2.0;   // the reference's functor: P = R~ (X - t)
+      // rotation columns: A * (dR_j X), or A * (dR~_j (X - t)) with t = -R~' t~
+      double y0 = x0, y1 = x1, y2 = x2;
+      if (model2) {
+        y0 += R[0] * T[9] + R[3] * T[10] + R[6] * T[11];
+        y1 += R[1] * T[9] + R[4] * T[10] + R[7] * T[11];
+        y2 += R[2] * T[9] + R[5] * T[10] + R[8] * T[11];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double* D = T + 16 + 9 * j;
+        const double v0 = D[0] * y0 + D[1] * y1 + D[2] * y2;
+        const double v1 = D[3] * y0 + D[4] * y1 + D[5] * y2;
+        const double v2 = D[6] * y0 + D[7] * y1 + D[8] * y2;
+        Fv[j] = A[0] * v0 + A[1] * v1 + A[2] * v2;
+        Fv[9 + j] = A[3] * v0 + A[4] * v1 + A[5] * v2;
+      }
+      if (model2) {
+        // dP/dt = -R~: the translation columns are -E; the intrinsics block is constant: zero columns
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Fv[3 + j] = -Ev[j]; Fv[12 + j] = -Ev[3 + j]; }
+#pragma unroll
+        for (int j = 6; j < 9; ++j) { Fv[j] = 0.0; Fv[9 + j] = 0.0; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Fv[3 + j] = A[j]; Fv[12 + j] = A[3 + j]; }
+        Fv[6] = d * px;         Fv[15] = d * py;
+        Fv[7] = f * n * px;     Fv[16] = f * n * py;
+        Fv[8] = f * n * n * px; Fv[17] = f * n * n * py;
       }
       if (sc) {
         const double* s = sc + 9 * (size_t)cam;

@@ -50,7 +50,23 @@ __device__ __forceinline__ void mf_stage_cam(double* dst, int cam, const double*
   for (int k = 0; k < 9; ++k) xs[k] = s[k] * xv[k];
 #pragma unroll
   for (int k = 0; k < 15; ++k) dst[k] = T[k];
-  const bool small = M[9] != 0.0;
+  if (M[9] == 2.0) {
+    // camera model of the reference's functor, P = R~ (X - t): F x = E (m' x X + tau') with m' = -M~ x_w,
+    // tau' = -(m' x t) - x_t, t = -R~' t~ (derivation: DESIGN.md, camera model #2); everything per observation is unchanged
+    double mm[3], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mm[i] = -(M[3 * i] * xs[0] + M[3 * i + 1] * xs[1] + M[3 * i + 2] * xs[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = -(T[i] * T[9] + T[3 + i] * T[10] + T[6 + i] * T[11]);
+    dst[15] = mm[0]; dst[16] = mm[1]; dst[17] = mm[2];
+    dst[18] = -(mm[1] * t[2] - mm[2] * t[1]) - xs[3];
+    dst[19] = -(mm[2] * t[0] - mm[0] * t[2]) - xs[4];
+    dst[20] = -(mm[0] * t[1] - mm[1] * t[0]) - xs[5];
+    dst[21] = 0.0; dst[22] = 0.0; dst[23] = 0.0;   // constant intrinsics
+    dst[24] = 0.0;
+    return;
+  }
+  const bool small = M[9] == 1.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) dst[15 + i] = M[3 * i] * xs[0] + M[3 * i + 1] * xs[1] + M[3 * i + 2] * xs[2];
 #pragma unroll
@@ -114,7 +130,7 @@ __device__ __forceinline__ void mf_geom(const double* cd, double x0, double x1, 
     g.E[3 + j] = A[3] * cd[j] + A[4] * cd[3 + j] + A[5] * cd[6 + j];
   }
   if (SMALL) {
-    const bool small = cd[24] != 0.0;
+    const bool small = cd[24] == 1.0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) g.Ep[j] = small ? A[j] : g.E[j];
   } else {
@@ -440,7 +456,24 @@ __device__ __forceinline__ void mf_blocks(const double* cd, double x0, double x1
     E[j] = A[0] * cd[j] + A[1] * cd[3 + j] + A[2] * cd[6 + j];
     E[3 + j] = A[3] * cd[j] + A[4] * cd[3 + j] + A[5] * cd[6 + j];
   }
-  const bool small = cd[24] != 0.0;
+  if (cd[24] == 2.0) {
+    // the reference's functor (P = R~ (X - t)): rotation columns ((t - X) x e_i)' M~, translation columns -e_i, constant
+    // intrinsics (zero columns); t = -R~' t~
+    const double t0 = -(cd[0] * cd[9] + cd[3] * cd[10] + cd[6] * cd[11]) - x0;
+    const double t1 = -(cd[1] * cd[9] + cd[4] * cd[10] + cd[7] * cd[11]) - x1;
+    const double t2 = -(cd[2] * cd[9] + cd[5] * cd[10] + cd[8] * cd[11]) - x2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double e0 = E[3 * i], e1 = E[3 * i + 1], e2 = E[3 * i + 2];
+      const double g0 = t1 * e2 - t2 * e1, g1 = t2 * e0 - t0 * e2, g2 = t0 * e1 - t1 * e0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) F[9 * i + j] = g0 * cd[15 + j] + g1 * cd[18 + j] + g2 * cd[21 + j];
+      F[9 * i + 3] = -e0; F[9 * i + 4] = -e1; F[9 * i + 5] = -e2;
+      F[9 * i + 6] = 0.0; F[9 * i + 7] = 0.0; F[9 * i + 8] = 0.0;
+    }
+    return;
+  }
+  const bool small = cd[24] == 1.0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const double e0 = small ? A[3 * i] : E[3 * i], e1 = small ? A[3 * i + 1] : E[3 * i + 1], e2 = small ? A[3 * i + 2] : E[3 * i + 2];
@@ -1074,9 +1107,19 @@ __global__ __launch_bounds__(256) void k_cam_reduce_mf(int n_cam, int cams_per_b
     if (lane < 9) {
       const double* T = ct + (size_t)kCamTabStride * c;
       const double* M = cm + 10 * (size_t)c;
-      const bool small = M[9] != 0.0;
+      const bool small = M[9] == 1.0;
       double r;
-      if (lane < 3) r = M[lane] * v[0] + M[3 + lane] * v[1] + M[6 + lane] * v[2];                       // (M' c)_lane
+      if (M[9] == 2.0) {
+        // the reference's functor: rotation part M~' (t x a - c), translation part -a, constant intrinsics; t = -R~' t~
+        if (lane < 3) {
+          const double t0 = -(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]);
+          const double t1 = -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11]);
+          const double t2 = -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11]);
+          const double u0 = t1 * v[5] - t2 * v[4] - v[0], u1 = t2 * v[3] - t0 * v[5] - v[1], u2 = t0 * v[4] - t1 * v[3] - v[2];
+          r = M[lane] * u0 + M[3 + lane] * u1 + M[6 + lane] * u2;
+        } else if (lane < 6) r = -v[lane];
+        else r = 0.0;
+      } else if (lane < 3) r = M[lane] * v[0] + M[3 + lane] * v[1] + M[6 + lane] * v[2];                // (M' c)_lane
       else if (lane < 6) {
         const int i = lane - 3;
         r = small ? v[3 + i] : (T[3 * i] * v[3] + T[3 * i + 1] * v[4] + T[3 * i + 2] * v[5]);           // (N a)_i

@@ -16,9 +16,30 @@ BAConstraint::BAConstraint(const Eigen::Vector3f &observation, const float *esti
     this->pose = Eigen::Map<const Eigen::Matrix4f>(estimatedPose);
 }
 
+namespace { bool g_reference_model = false; }
+void BAConstraint::useReferenceModel(bool on) { g_reference_model = on; }
+bool BAConstraint::referenceModel() { return g_reference_model; }
+
 template<typename T>
 bool BAConstraint::operator()(const T *const point, const T *const rot, const T *const tr, const T *const intrinsics,
                               T *residuals) const {
+    if (g_reference_model) {
+        // the reference's functor, expression by expression (src/BAConstraint.cpp:34-77); the inverse of the 4x4 extrinsic
+        // [R tr; 0 1] is [R^-1, -R^-1 tr; 0 1], so cam_point = R^-1 (point - tr) with R^-1 by cofactors
+        T R[9];
+        ceres::AngleAxisToRotationMatrix<T>(rot, R);   // column-major, as ceres
+        const T a00 = R[0], a01 = R[3], a02 = R[6], a10 = R[1], a11 = R[4], a12 = R[7], a20 = R[2], a21 = R[5], a22 = R[8];
+        const T c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const T id = T(1.0) / (a00 * c00 + a01 * c01 + a02 * c02);
+        const T y0 = point[0] - tr[0], y1 = point[1] - tr[1], y2 = point[2] - tr[2];
+        const T P0 = (c00 * y0 + (a02 * a21 - a01 * a22) * y1 + (a01 * a12 - a02 * a11) * y2) * id;
+        const T P1 = (c01 * y0 + (a00 * a22 - a02 * a20) * y1 + (a02 * a10 - a00 * a12) * y2) * id;
+        const T P2 = (c02 * y0 + (a01 * a20 - a00 * a21) * y1 + (a00 * a11 - a01 * a10) * y2) * id;
+        const T u = P0 / P2, v = P1 / P2;              // no sign flip (:67-68); the radial factor is computed and dropped (:69-70)
+        residuals[0] = T(double(observation(0))) - (intrinsics[0] * u + intrinsics[2]);
+        residuals[1] = T(double(observation(1))) - (intrinsics[1] * v + intrinsics[3]);
+        return true;
+    }
     const T &fx = intrinsics[0];
     const T &fy = intrinsics[1];
     const T &ox = intrinsics[2];

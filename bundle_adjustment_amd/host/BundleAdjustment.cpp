@@ -183,6 +183,12 @@ void BundleAdjustment::createProblem() {
     p.obs_cam = obs_cam.data();
     p.obs_pt = obs_pt.data();
     p.obs_xy = obs_xy.data();
+    // BA_CAMERA_MODEL=reference: the cost functor the reference has checked in (src/BAConstraint.cpp:15-80) instead of the BAL
+    // camera; with BA_REFERENCE_CONSTANT_BLOCKS=1 this is createProblem as it stands in the reference (:67-90)
+    const char *cmod = getenv("BA_CAMERA_MODEL");
+    const bool ref_model = cmod && std::string(cmod) == "reference";
+    p.camera_model = ref_model ? MIBA_MODEL_REFERENCE : MIBA_MODEL_BAL;
+    BAConstraint::useReferenceModel(ref_model);
     check(miba_set_problem(problem, &p), problem, "miba_set_problem");
 
     // The reference's createProblem, in its checked-in debugging state, fixes the intrinsics and the rotation

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MIBA_LIB", os.path.join(_HERE, "libmiba.so"))   # MIB
 (DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR,
  ITERATIVE_SCHUR, CGNR) = range(7)
 PRECOND_JACOBI, PRECOND_SCHUR_JACOBI = 0, 1
+MODEL_BAL, MODEL_REFERENCE = 0, 1   # miba_problem.camera_model
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2   # options.loss_type (ceres::HuberLoss / CauchyLoss with options.loss_scale)
 CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE = range(5)
 K_EVAL_JAC, K_EVAL_COST, K_SCHUR_INIT, K_SCHUR_MATVEC, K_BACKSUB = range(5)
@@ -46,7 +47,7 @@ class Problem(C.Structure):
                 ("R", C.POINTER(C.c_double)), ("T", C.POINTER(C.c_double)),
                 ("K", C.POINTER(C.c_double)), ("X", C.POINTER(C.c_double)),
                 ("obs_cam", C.POINTER(C.c_int32)), ("obs_pt", C.POINTER(C.c_int32)),
-                ("obs_xy", C.POINTER(C.c_double))]
+                ("obs_xy", C.POINTER(C.c_double)), ("camera_model", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -215,9 +216,9 @@ class Solver:
         except Exception:
             pass
 
-    def set_problem(self, cams, pts, obs_cam, obs_pt, obs_xy, K=None):
+    def set_problem(self, cams, pts, obs_cam, obs_pt, obs_xy, K=None, camera_model=0):
         """K: optional (n_cam, 6) intrinsics [fx fy ox oy k1 k2] handed over as they are instead of the BAL-shaped ones
-        built from cams"""
+        built from cams; camera_model: MODEL_BAL or MODEL_REFERENCE (the reference's live functor: K carries fx fy ox oy)"""
         R, T, Kb = split_cams(cams)
         K = Kb if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 6)
         X = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
@@ -226,7 +227,7 @@ class Solver:
         obs_xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
         self.n_cam, self.n_pt, self.n_obs = R.shape[0], X.shape[0], obs_cam.size
         p = Problem(self.n_cam, self.n_pt, self.n_obs, _dp(R), _dp(T), _dp(K), _dp(X),
-                    _ip(obs_cam), _ip(obs_pt), _dp(obs_xy))
+                    _ip(obs_cam), _ip(obs_pt), _dp(obs_xy), camera_model, 0)
         self._chk(lib().miba_set_problem(self._h, C.byref(p)), "miba_set_problem")
 
     def set_state(self, cams, pts, K=None):

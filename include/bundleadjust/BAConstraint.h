@@ -29,6 +29,12 @@ public:
     // prints the intermediate quantities of one evaluation (debugging aid of the reference)
     bool printOp(double * point, double * rot, double * tr, double * intrinsics, const float * estimatedPose) const;
 
+    // Which algebra the functor evaluates: false (default) the 9-parameter BAL camera, true the reference's functor as it
+    // is checked in (src/BAConstraint.cpp:15-80: [R | tr]^-1, fx fy ox oy, no distortion, observed - projected) — libmiba's
+    // camera model #2.  BundleAdjustment sets it from BA_CAMERA_MODEL=reference.
+    static void useReferenceModel(bool on);
+    static bool referenceModel();
+
 protected:
     const Eigen::Vector3f observation;
     Eigen::Matrix4f pose;

@@ -93,7 +93,18 @@ typedef struct {
   const int32_t* obs_cam;
   const int32_t* obs_pt;
   const double* obs_xy;
+  /* MIBA_MODEL_BAL (0, the default): the 9-parameter BAL camera of the north star (rotate, translate, -P.xy/P.z, radial
+   * distortion, f; residual predicted - observed).
+   * MIBA_MODEL_REFERENCE (1): the reference's cost functor as checked in, BAConstraint::operator() src/BAConstraint.cpp:15-80:
+   * P = [R(rot) | tr]^-1 [X; 1], projection (fx P.x/P.z + ox, fy P.y/P.z + oy), no distortion, residual observed - projected.
+   * Its intrinsics block (fx, fy, ox, oy, k1, k2) is always constant, as the reference marks it (src/BundleAdjustment.cpp:77);
+   * rotation and translation blocks are free unless miba_set_constant_blocks says otherwise.  Needs fx == fy (what the
+   * reference's own data has: src/VirtualSensor.cpp:37-39); k1, k2 are ignored, as the functor ignores them.  miba_evaluate
+   * returns the functor's residuals and the Jacobian columns rot, tr and three zero columns. */
+  int32_t camera_model;
+  int32_t reserved;
 } miba_problem;
+enum { MIBA_MODEL_BAL = 0, MIBA_MODEL_REFERENCE = 1 };
 
 /* preconditioner of the implicit-Schur PCG: block diagonal of the camera part B = F'F + D^2 (Ceres' JACOBI,
  * the default the reference runs with) or of the Schur complement itself (Ceres' SCHUR_JACOBI) */

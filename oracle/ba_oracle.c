@@ -53,6 +53,8 @@ void bao_default_options(bao_options* o) {
   o->eta = 1e-1;
   o->cam_const = NULL;
   o->loss_type = BAO_LOSS_NONE;
+  o->camera_model = BAO_MODEL_BAL;
+  o->cam_k4 = NULL;
   o->loss_scale = 1.0;
 }
 
@@ -163,6 +165,116 @@ void bao_project(const double* cam9, const double* X, const double* obs2, double
   }
 }
 
+/* R (row-major) and dR/dw_j of ceres::AngleAxisToRotationMatrix, both branches */
+static void rotation_and_derivative(const double* w, double* R, double dR[3][9]) {
+  const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (theta2 > DBL_EPSILON) {
+    const double theta = sqrt(theta2);
+    const double c = cos(theta), s = sin(theta);
+    const double omc = (c > 0.0) ? s * s / (1.0 + c) : 1.0 - c;
+    const double k[3] = {w[0] / theta, w[1] / theta, w[2] / theta};
+    R[0] = c + k[0] * k[0] * omc;        R[1] = -k[2] * s + k[0] * k[1] * omc; R[2] = k[1] * s + k[0] * k[2] * omc;
+    R[3] = k[2] * s + k[0] * k[1] * omc; R[4] = c + k[1] * k[1] * omc;         R[5] = -k[0] * s + k[1] * k[2] * omc;
+    R[6] = -k[1] * s + k[0] * k[2] * omc; R[7] = k[0] * s + k[1] * k[2] * omc; R[8] = c + k[2] * k[2] * omc;
+    for (int j = 0; j < 3; ++j) {
+      double dk[3];
+      for (int i = 0; i < 3; ++i) dk[i] = ((i == j ? 1.0 : 0.0) - k[i] * k[j]) / theta;
+      const double kj = k[j];   /* d theta / d w_j */
+      /* d/dw_j [ c I + s [k]x + (1-c) k k' ] */
+      const double v[3] = {c * kj * k[0] + s * dk[0], c * kj * k[1] + s * dk[1], c * kj * k[2] + s * dk[2]};
+      for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q)
+          dR[j][3 * r + q] = (r == q ? -s * kj : 0.0) + s * kj * k[r] * k[q] + omc * (dk[r] * k[q] + k[r] * dk[q]);
+      dR[j][1] += -v[2]; dR[j][2] += v[1];
+      dR[j][3] += v[2];  dR[j][5] += -v[0];
+      dR[j][6] += -v[1]; dR[j][7] += v[0];
+    }
+  } else {
+    R[0] = 1.0; R[1] = -w[2]; R[2] = w[1];
+    R[3] = w[2]; R[4] = 1.0; R[5] = -w[0];
+    R[6] = -w[1]; R[7] = w[0]; R[8] = 1.0;
+    memset(dR, 0, sizeof(double) * 27);
+    dR[0][5] = -1.0; dR[0][7] = 1.0;
+    dR[1][2] = 1.0;  dR[1][6] = -1.0;
+    dR[2][1] = -1.0; dR[2][3] = 1.0;
+  }
+}
+
+static void inv3(const double* a, double* inv) {
+  const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
+  inv[0] = c00 * id; inv[1] = (a[2] * a[7] - a[1] * a[8]) * id; inv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+  inv[3] = c01 * id; inv[4] = (a[0] * a[8] - a[2] * a[6]) * id; inv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+  inv[6] = c02 * id; inv[7] = (a[1] * a[6] - a[0] * a[7]) * id; inv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+void bao_project2(const double* cam6, const double* k4, const double* X, const double* obs2, double* r2, double* Jc18, double* Jp6) {
+  const double* t = cam6 + 3;
+  const double fx = k4[0], fy = k4[1], ox = k4[2], oy = k4[3];
+  double R[9], dR[3][9], Ri[9];
+  rotation_and_derivative(cam6, R, dR);           /* src/BAConstraint.cpp:35 */
+  inv3(R, Ri);                                    /* :46 (the 4x4 inverse of [R t; 0 1] is [R^-1, -R^-1 t; 0 1]) */
+  const double Y[3] = {X[0] - t[0], X[1] - t[1], X[2] - t[2]};
+  double P[3];
+  for (int i = 0; i < 3; ++i) P[i] = Ri[3 * i] * Y[0] + Ri[3 * i + 1] * Y[1] + Ri[3 * i + 2] * Y[2];   /* :57 */
+  const double iz = 1.0 / P[2];
+  const double px = P[0] * iz, py = P[1] * iz;    /* :67-68 */
+  r2[0] = obs2[0] - (fx * px + ox);               /* :72-76 */
+  r2[1] = obs2[1] - (fy * py + oy);
+  if (!Jc18 && !Jp6) return;
+  /* d r / d P */
+  const double A[6] = {-fx * iz, 0.0, fx * P[0] * iz * iz, 0.0, -fy * iz, fy * P[1] * iz * iz};
+  if (Jp6)
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) Jp6[3 * i + j] = A[3 * i] * Ri[j] + A[3 * i + 1] * Ri[3 + j] + A[3 * i + 2] * Ri[6 + j];
+  if (Jc18) {
+    memset(Jc18, 0, sizeof(double) * 18);
+    for (int j = 0; j < 3; ++j) {
+      /* dP/dw_j = -R^-1 dR_j P */
+      double u[3], v[3];
+      for (int i = 0; i < 3; ++i) u[i] = dR[j][3 * i] * P[0] + dR[j][3 * i + 1] * P[1] + dR[j][3 * i + 2] * P[2];
+      for (int i = 0; i < 3; ++i) v[i] = -(Ri[3 * i] * u[0] + Ri[3 * i + 1] * u[1] + Ri[3 * i + 2] * u[2]);
+      for (int i = 0; i < 2; ++i) {
+        Jc18[9 * i + j] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+        /* dP/dt_j = -R^-1 e_j */
+        Jc18[9 * i + 3 + j] = -(A[3 * i] * Ri[j] + A[3 * i + 1] * Ri[3 + j] + A[3 * i + 2] * Ri[6 + j]);
+      }
+    }
+  }
+}
+
+/* model dispatch of the solver: per-camera intrinsics of the reference model ride in the problem (NULL: BAL) */
+static const double* g_unused_k4 = NULL;
+static inline void project_any(const double* k4, int c, const double* cams, const double* X, const double* obs, double* r, double* F,
+                               double* E) {
+  if (k4) bao_project2(cams + 9 * (size_t)c, k4 + 4 * (size_t)c, X, obs, r, F, E);
+  else bao_project(cams + 9 * (size_t)c, X, obs, r, F, E);
+}
+
+double bao_evaluate2(int n_cam, int n_pt, int64_t n_obs, const double* cams, const double* k4, const double* pts,
+                     const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                     double* r, double* Jc, double* Jp, double* grad_cam, double* grad_pt) {
+  double cost = 0.0;
+  (void)g_unused_k4;
+  if (grad_cam) memset(grad_cam, 0, sizeof(double) * 9 * (size_t)n_cam);
+  if (grad_pt) memset(grad_pt, 0, sizeof(double) * 3 * (size_t)n_pt);
+  const int want_j = Jc || Jp || grad_cam || grad_pt;
+  for (int64_t i = 0; i < n_obs; ++i) {
+    double rr[2], jc[18], jp[6];
+    const int c = obs_cam[i], p = obs_pt[i];
+    project_any(k4, c, cams, pts + 3 * (size_t)p, obs_xy + 2 * i, rr, want_j ? jc : NULL, want_j ? jp : NULL);
+    cost += rr[0] * rr[0] + rr[1] * rr[1];
+    if (r) { r[2 * i] = rr[0]; r[2 * i + 1] = rr[1]; }
+    if (Jc) memcpy(Jc + 18 * i, jc, sizeof(jc));
+    if (Jp) memcpy(Jp + 6 * i, jp, sizeof(jp));
+    if (grad_cam)
+      for (int k = 0; k < 9; ++k) grad_cam[9 * (size_t)c + k] += jc[k] * rr[0] + jc[9 + k] * rr[1];
+    if (grad_pt)
+      for (int k = 0; k < 3; ++k) grad_pt[3 * (size_t)p + k] += jp[k] * rr[0] + jp[3 + k] * rr[1];
+  }
+  return 0.5 * cost;
+}
+
 double bao_evaluate(int n_cam, int n_pt, int64_t n_obs, const double* cams, const double* pts,
                     const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                     double* r, double* Jc, double* Jp, double* grad_cam, double* grad_pt) {
@@ -204,6 +316,7 @@ typedef struct {
   double* tbuf;    /* per-thread camera accumulators: n_thr * 81 * n_cam */
   int loss_type;   /* BAO_LOSS_*: applied to every residual block */
   double loss_a;
+  const double* k4; /* [n_cam][4] fx fy ox oy: the reference's camera model (bao_project2); NULL: BAL */
 } prob_t;
 
 /* ceres::HuberLoss / CauchyLoss ::Evaluate on s = |r|^2: rho(s) and rho'(s) (rho'' <= 0 for both, so Ceres'
@@ -298,7 +411,7 @@ static double prob_evaluate(prob_t* P, const double* cams, const double* pts, co
       double* r = P->r + 2 * s;
       double* F = P->F + 18 * s;
       double* E = P->E + 6 * s;
-      bao_project(cams + 9 * (size_t)c, pts + 3 * (size_t)p, P->oxy + 2 * s, r, F, E);
+      project_any(P->k4, c, cams, pts + 3 * (size_t)p, P->oxy + 2 * s, r, F, E);
       if (P->loss_type != BAO_LOSS_NONE) {
         double rho, rho1;
         loss_eval(P->loss_type, P->loss_a, r[0] * r[0] + r[1] * r[1], &rho, &rho1);
@@ -332,7 +445,7 @@ static double prob_cost(const prob_t* P, const double* cams, const double* pts) 
   for (int p = 0; p < P->n_pt; ++p) {
     for (int64_t s = P->pt_off[p]; s < P->pt_off[p + 1]; ++s) {
       double r[2];
-      bao_project(cams + 9 * (size_t)P->cam[s], pts + 3 * (size_t)p, P->oxy + 2 * s, r, NULL, NULL);
+      project_any(P->k4, P->cam[s], cams, pts + 3 * (size_t)p, P->oxy + 2 * s, r, NULL, NULL);
       double rho = r[0] * r[0] + r[1] * r[1], rho1;
       if (P->loss_type != BAO_LOSS_NONE) loss_eval(P->loss_type, P->loss_a, rho, &rho, &rho1);
       cost += rho;
@@ -876,6 +989,12 @@ int bao_linear_step(int n_cam, int n_pt, int64_t n_obs, const double* cams, cons
   int rc = prob_build(&P, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, opt->num_threads);
   if (rc) return rc;
   P.loss_type = opt->loss_type; P.loss_a = opt->loss_scale;
+  if (opt->camera_model == BAO_MODEL_REFERENCE) {
+    /* the reference keeps the intrinsics block of every camera constant (src/BundleAdjustment.cpp:77) */
+    if (!opt->cam_k4 || !opt->cam_const) { prob_free(&P); return -3; }
+    for (int c = 0; c < n_cam; ++c) if (!opt->cam_const[3 * (size_t)c + 2]) { prob_free(&P); return -3; }
+    P.k4 = opt->cam_k4;
+  }
   if (schur_alloc(&S, n_cam, n_pt)) { prob_free(&P); return -1; }
   double* dc = (double*)malloc(sizeof(double) * 9 * ((size_t)n_cam + 1));
   double* dp = (double*)malloc(sizeof(double) * 3 * ((size_t)n_pt + 1));
@@ -908,6 +1027,12 @@ int bao_solve(int n_cam, int n_pt, int64_t n_obs, double* cams, double* pts,
   int rc = prob_build(&P, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, opt->num_threads);
   if (rc) return rc;
   P.loss_type = opt->loss_type; P.loss_a = opt->loss_scale;
+  if (opt->camera_model == BAO_MODEL_REFERENCE) {
+    /* the reference keeps the intrinsics block of every camera constant (src/BundleAdjustment.cpp:77) */
+    if (!opt->cam_k4 || !opt->cam_const) { prob_free(&P); return -3; }
+    for (int c = 0; c < n_cam; ++c) if (!opt->cam_const[3 * (size_t)c + 2]) { prob_free(&P); return -3; }
+    P.k4 = opt->cam_k4;
+  }
   if (schur_alloc(&S, n_cam, n_pt)) { prob_free(&P); return -1; }
   const size_t nc9 = 9 * (size_t)n_cam, np3 = 3 * (size_t)n_pt;
   double* xc = (double*)malloc(sizeof(double) * nc9);   /* current x */

@@ -69,7 +69,14 @@ typedef struct {
      does for rho'' <= 0: both multiplied by sqrt(rho') */
   int loss_type;
   double loss_scale;
+  /* camera model: BAO_MODEL_BAL (the 9-parameter BAL camera, default) or BAO_MODEL_REFERENCE, the reference's live functor
+     (src/BAConstraint.cpp:15-80: inverse extrinsic, fx fy ox oy, no distortion, observed - projected; bao_project2).  Its
+     intrinsics block is constant, as the reference marks it (src/BundleAdjustment.cpp:77): cam_k4 = [n_cam][4] fx fy ox oy;
+     the camera vector's entries 6..8 are not used and their columns are zero. */
+  int camera_model;
+  const double* cam_k4;
 } bao_options;
+enum { BAO_MODEL_BAL = 0, BAO_MODEL_REFERENCE = 1 };
 
 /* ceres::HuberLoss(a): rho(s) = s (s <= a^2), 2 a sqrt(s) - a^2 otherwise; ceres::CauchyLoss(a): a^2 log(1 + s/a^2) */
 enum { BAO_LOSS_NONE = 0, BAO_LOSS_HUBER = 1, BAO_LOSS_CAUCHY = 2 };
@@ -105,6 +112,18 @@ typedef struct {
 } bao_summary;
 
 void bao_default_options(bao_options* o);
+
+/* One observation of the reference's live functor, BAConstraint::operator() (src/BAConstraint.cpp:15-80), restated line by
+ * line: R = AngleAxisToRotationMatrix(rot) (:35, Ceres' two branches), extr = [R | tr; 0 0 0 1] (:41-44), P = extr^-1 [X; 1]
+ * (:46-57), Pimg = P.xy / P.z (:67-68, no sign flip), the radial factor is computed and not used (:69-70), Pproj = K Pimg
+ * (:72), residual = observation - Pproj (:73).  cam6 = rot[3], tr[3]; k4 = fx fy ox oy.
+ * Jc18: 2 x 9 row-major with columns rot 0..2, tr 3..5 and three zero columns (the intrinsics block is constant); Jp6: 2 x 3.
+ * Derivative of the inverse as autodiff sees it: d(R^-1) = -R^-1 dR R^-1. */
+void bao_project2(const double* cam6, const double* k4, const double* X, const double* obs2, double* r2, double* Jc18, double* Jp6);
+/* bao_evaluate for either model: k4 NULL = BAL, else the reference's model with cams = [n_cam][9] (entries 6..8 unused) */
+double bao_evaluate2(int n_cam, int n_pt, int64_t n_obs, const double* cams, const double* k4, const double* pts,
+                     const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                     double* r, double* Jc, double* Jp, double* grad_cam, double* grad_pt);
 
 /* One observation of the 9-parameter BAL camera (SURVEY.md App. A.2-A.4;
  * block order follows BAConstraint.cpp:16,83: point, rot, tr, intrinsics).

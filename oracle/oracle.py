@@ -15,6 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "libba_oracle.so")
 ITERATIVE_SCHUR, DENSE_SCHUR, DENSE_NORMAL = 0, 1, 2
 JACOBI, SCHUR_JACOBI = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2
+MODEL_BAL, MODEL_REFERENCE = 0, 1   # options.camera_model (MODEL_REFERENCE: src/BAConstraint.cpp:15-80, bao_project2)
 
 
 class Options(C.Structure):
@@ -40,6 +41,8 @@ class Options(C.Structure):
         ("cam_const", C.c_void_p),
         ("loss_type", C.c_int),
         ("loss_scale", C.c_double),
+        ("camera_model", C.c_int),
+        ("cam_k4", C.c_void_p),
     ]
 
 
@@ -107,6 +110,16 @@ def default_options(**kw):
     o = Options()
     lib().bao_default_options(C.byref(o))
     cc = kw.pop("cam_const", None)
+    k4 = kw.pop("cam_k4", None)
+    if k4 is not None:
+        # the reference's live camera model (bao_project2): fx fy ox oy per camera, intrinsics constant
+        o._cam_k4 = np.ascontiguousarray(k4, dtype=np.float64).reshape(-1, 4)
+        o.cam_k4 = o._cam_k4.ctypes.data
+        o.camera_model = MODEL_REFERENCE
+        if cc is None:
+            cc = np.zeros((o._cam_k4.shape[0], 3), np.uint8)
+        cc = np.array(cc).astype(np.uint8).reshape(-1, 3)
+        cc[:, 2] = 1
     if cc is not None:
         # [n_cam][3] flags (rotation, translation, intrinsics); the array is kept alive on the options object
         o._cam_const = np.ascontiguousarray(np.asarray(cc).astype(np.uint8))
@@ -127,7 +140,19 @@ def project(cam9, X, obs2, jac=True):
     return r, jc, jp
 
 
-def evaluate(cams, pts, obs_cam, obs_pt, obs_xy, jac=True, grad=True):
+def project2(cam6, k4, X, obs2, jac=True):
+    """the reference's live functor (src/BAConstraint.cpp:15-80): cam6 = rot, tr; k4 = fx fy ox oy"""
+    cam6, k4, X, obs2 = _f64(cam6), _f64(k4), _f64(X), _f64(obs2)
+    r = np.zeros(2)
+    jc = np.zeros((2, 9)) if jac else None
+    jp = np.zeros((2, 3)) if jac else None
+    lib().bao_project2(_p(cam6), _p(k4), _p(X), _p(obs2), _p(r), _p(jc), _p(jp))
+    return r, jc, jp
+
+
+def evaluate(cams, pts, obs_cam, obs_pt, obs_xy, jac=True, grad=True, cam_k4=None):
+    if cam_k4 is not None:
+        return _evaluate2(cams, cam_k4, pts, obs_cam, obs_pt, obs_xy, jac, grad)
     cams, pts, obs_xy = _f64(cams), _f64(pts), _f64(obs_xy)
     obs_cam, obs_pt = _i32(obs_cam), _i32(obs_pt)
     n_cam, n_pt, n_obs = cams.size // 9, pts.size // 3, obs_cam.size
@@ -139,6 +164,22 @@ def evaluate(cams, pts, obs_cam, obs_pt, obs_xy, jac=True, grad=True):
     cost = lib().bao_evaluate(C.c_int(n_cam), C.c_int(n_pt), C.c_int64(n_obs), _p(cams), _p(pts),
                               _p(obs_cam, C.c_int32), _p(obs_pt, C.c_int32), _p(obs_xy),
                               _p(r), _p(jc), _p(jp), _p(gc), _p(gp))
+    return dict(cost=cost, r=r, Jc=jc, Jp=jp, grad_cam=gc, grad_pt=gp)
+
+
+def _evaluate2(cams, k4, pts, obs_cam, obs_pt, obs_xy, jac, grad):
+    cams, k4, pts, obs_xy = _f64(cams), _f64(k4), _f64(pts), _f64(obs_xy)
+    obs_cam, obs_pt = _i32(obs_cam), _i32(obs_pt)
+    n_cam, n_pt, n_obs = cams.size // 9, pts.size // 3, obs_cam.size
+    r = np.zeros((n_obs, 2))
+    jc = np.zeros((n_obs, 2, 9)) if jac else None
+    jp = np.zeros((n_obs, 2, 3)) if jac else None
+    gc = np.zeros((n_cam, 9)) if grad else None
+    gp = np.zeros((n_pt, 3)) if grad else None
+    lib().bao_evaluate2.restype = C.c_double
+    cost = lib().bao_evaluate2(C.c_int(n_cam), C.c_int(n_pt), C.c_int64(n_obs), _p(cams), _p(k4), _p(pts),
+                               _p(obs_cam, C.c_int32), _p(obs_pt, C.c_int32), _p(obs_xy),
+                               _p(r), _p(jc), _p(jp), _p(gc), _p(gp))
     return dict(cost=cost, r=r, Jc=jc, Jp=jp, grad_cam=gc, grad_pt=gp)
 
 

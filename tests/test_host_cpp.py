@@ -269,3 +269,64 @@ def test_app_main_on_several_shards(tmp_path):
         assert open(d / ("mesh_ITERATIVE_SCHUR_%d.ply" % last)).read() == open(d / "constrainTransReal.ply").read()
     assert finals["one"][1] == finals["three"][1]
     assert abs(finals["one"][0] - finals["three"][0]) <= 1e-8 * finals["one"][0]
+
+
+def test_reference_functor_autodiff_matches_mpmath():
+    """The reference's checked-in functor (src/BAConstraint.cpp:15-80), as the host mirror evaluates it with dual numbers
+    through BAConstraint::create, against the 80-digit vectors of the same text (camera model #2)."""
+    g = json.load(open(os.path.join(GOLD, "proj2_golden.json")))
+    lines = [" ".join(c["cam_hex"] + c["k4_hex"] + c["X_hex"] + c["obs_hex"]) for c in g["cases"]]
+    out = subprocess.run([CHECK, "--model2"], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0
+    rows = [[float.fromhex(t) for t in ln.split()] for ln in out.stdout.strip().split("\n")]
+    assert len(rows) == len(g["cases"])
+    for row, c in zip(rows, g["cases"]):
+        R = np.array([float(v) for v in c["r"]])
+        JC = np.array([[float(v) for v in r_] for r_ in c["Jc"]])
+        JP = np.array([[float(v) for v in r_] for r_ in c["Jp"]])
+        obs = np.array([float.fromhex(h) for h in c["obs_hex"]])
+        r = np.array(row[0:2]); jr = np.array(row[2:8]).reshape(2, 3); jt = np.array(row[8:14]).reshape(2, 3)
+        jp = np.array(row[14:20]).reshape(2, 3)
+        theta = np.linalg.norm([float.fromhex(h) for h in c["cam_hex"][:3]])
+        tol = 1e-10 if (c["small_angle"] or theta > 1e-3) else 1e-6   # autodiff differentiates (1 - cos) literally
+        assert np.abs(r - R).max() / max(1.0, np.abs(obs - R).max()) <= 1e-12
+        assert rel(jr, JC[:, 0:3]) <= tol and rel(jt, JC[:, 3:6]) <= tol and rel(jp, JP) <= tol
+        assert row[20] == 0.0 and row[21] == 0.0   # the radial factor is computed and dropped: no dependence on k1, k2
+
+
+@pytest.mark.gpu
+def test_app_main_with_the_reference_functor_and_marks(tmp_path, oracle):
+    """createProblem as it stands in the reference (src/BundleAdjustment.cpp:67-90): the checked-in functor
+    (BA_CAMERA_MODEL=reference) and its constant-block marks (BA_REFERENCE_CONSTANT_BLOCKS=1: rotations and intrinsics of
+    every camera, all of camera 0): only translations and points move.  A BAL file read through that functor is not a
+    sensible scene (no sign flip, poses inverted), so the data here is generated for it: final cost against the oracle
+    with the same model, marks and glibc noise."""
+    rng = np.random.default_rng(21)
+    n_cam, n_pt = 10, 300
+    pr = synth.make_problem(n_cam, n_pt, 1400, seed=23)
+    w = rng.normal(0, 0.2, (n_cam, 3)); t = rng.normal(0, 0.3, (n_cam, 3))
+    f = rng.uniform(500, 560, n_cam)
+    pts = np.stack([rng.uniform(-1.5, 1.5, n_pt), rng.uniform(-1.2, 1.2, n_pt), rng.uniform(3.0, 6.0, n_pt)], 1)
+    cams = np.concatenate([w, t, f[:, None], np.zeros((n_cam, 2))], 1).astype(np.float32).astype(np.float64)
+    pts = pts.astype(np.float32).astype(np.float64)
+    k4 = np.stack([cams[:, 6], cams[:, 6], np.zeros(n_cam), np.zeros(n_cam)], 1)   # a BAL file carries no principal point
+    xy = np.zeros((1400, 2))
+    for i in range(1400):
+        r, _, _ = oracle.project2(cams[pr["obs_cam"][i], 0:6], k4[pr["obs_cam"][i]], pts[pr["obs_pt"][i]], [0.0, 0.0], jac=False)
+        xy[i] = -r
+    xy = (xy + rng.normal(0, 0.3, xy.shape)).astype(np.float32).astype(np.float64)
+    prob = dict(pr, cams=cams, pts=pts, obs_xy=xy)
+    path = str(tmp_path / "problem-10-300-pre.txt")
+    synth.write_bal(path, prob)
+    env = dict(os.environ, BA_SIGMA_CAM="0.004", BA_SIGMA_X="0.03", BA_CAMERA_MODEL="reference", BA_REFERENCE_CONSTANT_BLOCKS="1")
+    out = subprocess.run([MAIN, path, "SPARSE_SCHUR", "10"], capture_output=True, text=True, timeout=120, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    m = re.search(r"FINAL_COST (\S+) ITERATIONS (\d+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    R, T, K, X = oracle.bal_initialize(cams.astype(np.float32), pts.astype(np.float32), 0.004, 0.03, seed=1)
+    cams0 = np.concatenate([R, T, K[:, 0:1], K[:, 4:5], K[:, 5:6]], 1)
+    cc = np.zeros((n_cam, 3), np.uint8); cc[:, 0] = 1; cc[:, 2] = 1; cc[0, :] = 1
+    _, _, oits, osumm = oracle.solve(cams0, X, pr["obs_cam"], pr["obs_pt"], xy,
+                                     oracle.default_options(max_num_iterations=10, linear_solver=oracle.DENSE_SCHUR, cam_const=cc, cam_k4=K[:, 0:4]))
+    assert abs(float(m.group(1)) - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"], (m.group(1), osumm)
+    assert osumm["final_cost"] < 0.7 * osumm["initial_cost"]

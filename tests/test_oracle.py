@@ -216,3 +216,27 @@ def test_robust_loss_matches_numpy_dense_lm(oracle, loss, solver):
         assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-4 * b["gradient_max_norm"] + 1e-9
         assert abs(a["step_norm"] - b["step_norm"]) <= 1e-4 * b["step_norm"] + 1e-12
     assert abs(summ["final_cost"] - gsum["final_cost"]) <= 1e-6 * gsum["final_cost"]
+
+
+def test_reference_functor_matches_mpmath(oracle):
+    """Camera model #2: the oracle's restatement of the reference's LIVE functor (src/BAConstraint.cpp:15-80: inverse
+    extrinsic, fx fy ox oy, no distortion, observed - projected) against 80-digit mpmath vectors of the same text
+    (tests/golden/proj2_golden.json, tools/gen_golden2.py)."""
+    g = json.load(open(os.path.join(GOLD, "proj2_golden.json")))
+    assert g["n"] >= 200
+    n_small = 0
+    for i, c in enumerate(g["cases"]):
+        cam = [float.fromhex(h) for h in c["cam_hex"]]
+        k4 = [float.fromhex(h) for h in c["k4_hex"]]
+        X = [float.fromhex(h) for h in c["X_hex"]]
+        obs = [float.fromhex(h) for h in c["obs_hex"]]
+        r, jc, jp = oracle.project2(cam, k4, X, obs)
+        R = np.array([float(v) for v in c["r"]])
+        JC = np.array([[float(v) for v in row] for row in c["Jc"]])
+        JP = np.array([[float(v) for v in row] for row in c["Jp"]])
+        n_small += c["small_angle"]
+        pred = max(1.0, np.abs(np.array(obs) - R).max())
+        assert np.abs(r - R).max() / pred <= 1e-12, i
+        assert rel(jc[:, 0:3], JC[:, 0:3]) <= 1e-11 and rel(jc[:, 3:6], JC[:, 3:6]) <= 1e-12 and rel(jp, JP) <= 1e-12, (i, c["small_angle"])
+        assert np.all(jc[:, 6:9] == 0.0)   # the intrinsics block is constant in this model
+    assert n_small >= 6
