@@ -29,6 +29,7 @@
 #include "miba_dense.hpp"
 #include "miba_plan.hpp"
 #include "miba_comm.hpp"
+#include "miba_sort.hpp"
 
 using namespace miba;
 
@@ -1331,6 +1332,62 @@ int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* ow
   return MIBA_OK;
 }
 
+// PlanSorter of build_plan on a GPU: the valid observations ordered by (point in tile order, camera), stable, by a rocPRIM
+// radix sort.  Returns non-zero (the planner then sorts on its host threads) when the device cannot hold the scratch.
+struct DeviceSortCtx { int device; hipStream_t st; };
+static int device_plan_sort(void* ctx, int64_t n_obs, int32_t n_pt, const int32_t* obs_cam, const int32_t* obs_pt, const uint8_t* ok,
+                            const int32_t* sorted_of, int32_t n_act, int64_t n_valid, int64_t* obs_sorted) {
+  const DeviceSortCtx& C = *(const DeviceSortCtx*)ctx;
+  if (n_obs < 1 || n_obs >= ((int64_t)1 << 32) || hipSetDevice(C.device) != hipSuccess) return 1;
+  const size_t n = (size_t)n_obs;
+  int32_t *d_cam = nullptr, *d_pt = nullptr, *d_so = nullptr;
+  uint8_t* d_ok = nullptr;
+  uint64_t *k0 = nullptr, *k1 = nullptr;
+  uint32_t *v0 = nullptr, *v1 = nullptr;
+  auto cleanup = [&]() {
+    (void)hipFree(d_cam); (void)hipFree(d_pt); (void)hipFree(d_so); (void)hipFree(d_ok);
+    (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(v1);
+  };
+  hipError_t e = hipMalloc(&d_cam, n * 4);
+  if (e == hipSuccess) e = hipMalloc(&d_pt, n * 4);
+  if (e == hipSuccess) e = hipMalloc(&d_so, sizeof(int32_t) * (size_t)n_pt);
+  if (e == hipSuccess) e = hipMalloc(&d_ok, n);
+  if (e == hipSuccess) e = hipMalloc(&k0, n * 8);
+  if (e == hipSuccess) e = hipMalloc(&k1, n * 8);
+  if (e == hipSuccess) e = hipMalloc(&v0, n * 4);
+  if (e == hipSuccess) e = hipMalloc(&v1, n * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_cam, obs_cam, n * 4, hipMemcpyHostToDevice, C.st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pt, obs_pt, n * 4, hipMemcpyHostToDevice, C.st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_so, sorted_of, sizeof(int32_t) * (size_t)n_pt, hipMemcpyHostToDevice, C.st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ok, ok, n, hipMemcpyHostToDevice, C.st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C.st, n_obs, d_cam, d_pt, d_ok, d_so, k0, v0);
+    e = hipGetLastError();
+  }
+  // key bits: 24 for the camera, enough for the point ranks, and the all-ones key of the filtered observations sorts last
+  // only if its bits are inside the sorted range: sort all 64 bits when anything was filtered
+  int end_bit = 24;
+  while (end_bit < 64 && ((uint64_t)1 << (end_bit - 24)) < (uint64_t)std::max<int32_t>(1, n_act)) ++end_bit;
+  if (n_valid != n_obs) end_bit = 64;
+  if (e == hipSuccess) e = device_sort_pairs(k0, k1, v0, v1, n, end_bit, C.st);
+  std::vector<uint32_t> out;
+  if (e == hipSuccess) {
+    out.resize((size_t)n_valid);
+    e = hipMemcpyAsync(out.data(), v1, (size_t)n_valid * 4, hipMemcpyDeviceToHost, C.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(C.st);
+  }
+  cleanup();
+  if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
+  plan_parallel_for(n_valid, [&](int64_t a, int64_t b) { for (int64_t j = a; j < b; ++j) obs_sorted[j] = (int64_t)out[(size_t)j]; });
+  return 0;
+}
+
+// MIBA_DEVICE_PLAN=0 keeps the whole repack on the host threads (the planner's own sort, host-built measurement arrays)
+static bool device_repack_wanted() {
+  const char* e = getenv("MIBA_DEVICE_PLAN");
+  return !(e && e[0] == '0');
+}
+
 static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_ptr<Plan> shared) {
   if (!h || !p) return fail(h, MIBA_ERR_INVALID, "null argument");
   if (!p->R || !p->T || !p->K || !p->X || (p->n_obs > 0 && (!p->obs_cam || !p->obs_pt || !p->obs_xy)))
@@ -1361,8 +1418,11 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   // the ranks of a single-process group share one plan (built once by the group), a stand-alone rank builds its own
   if (shared) h->plan_sp = shared; else h->plan_sp = std::make_shared<Plan>();
   Plan& P = h->plan_ref();
+  const bool dev_repack = device_repack_wanted();
+  DeviceSortCtx sort_ctx{h->device, h->st};
+  const PlanSorter sorter{device_plan_sort, &sort_ctx};
   int rc = shared ? 0 : build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->cfg.world_size,
-                                   po ? atoi(po) : 1);
+                                   po ? atoi(po) : 1, dev_repack ? &sorter : nullptr);
   if (rc) return fail(h, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", rc);
   PlanLap lap;
   h->n_cam = p->n_cam;
@@ -1401,8 +1461,8 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
     for (int64_t e = 0; e < n_rows; ++e) slab_row[e] = cur[P.tile_cams[tc0 + e]]++;
   }
   // observations in chunk-SoA order, point ranges
-  std::vector<double> oxy((size_t)(h->n_slots ? h->n_slots : 1) * 2, 0.0);
-  plan_parallel_for(h->n_slots, [&](int64_t a, int64_t b) {
+  std::vector<double> oxy(dev_repack ? (size_t)1 : (size_t)(h->n_slots ? h->n_slots : 1) * 2, 0.0);
+  if (!dev_repack) plan_parallel_for(h->n_slots, [&](int64_t a, int64_t b) {
     for (int64_t s = a; s < b; ++s) {
       const int64_t o = P.slot_orig[h->slot_base + s];
       if (o < 0) continue;
@@ -1432,9 +1492,9 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   lap("local arrays (oxy, ranges)");
   // camera-major copy of the local observations, cut into segments of at most kSegObs observations of one camera
   std::vector<int4> segv;
-  std::vector<int32_t> cmo_pt((size_t)(h->n_obs_local ? h->n_obs_local : 1)), cam_seg_off((size_t)p->n_cam + 1, 0);
-  std::vector<double2> cmo_xy((size_t)(h->n_obs_local ? h->n_obs_local : 1));
-  {
+  std::vector<int32_t> cmo_pt(dev_repack ? (size_t)1 : (size_t)(h->n_obs_local ? h->n_obs_local : 1)), cam_seg_off((size_t)p->n_cam + 1, 0);
+  std::vector<double2> cmo_xy(dev_repack ? (size_t)1 : (size_t)(h->n_obs_local ? h->n_obs_local : 1));
+  if (!dev_repack) {
     // stable counting sort of the local observations by camera, the points cut into R ranges that are counted
     // and scattered by R threads (ascending point order inside every camera is kept)
     const int R = 16;
@@ -1499,8 +1559,9 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   for (size_t i = 0; i < tiles.size(); ++i) if (tiles[i].giant) giant.push_back((int32_t)i);
   h->n_giant = (int32_t)giant.size();
   ALLOC(h->d_giant, giant.size());
-  ALLOC(h->d_seg, segv.size()); ALLOC(h->d_cmo_pt, cmo_pt.size()); ALLOC(h->d_cmo_xy, cmo_xy.size());
-  ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_cfree, 9 * nc); ALLOC(h->d_slabB, (size_t)kK2W * segv.size());
+  ALLOC(h->d_cmo_pt, h->n_obs_local ? h->n_obs_local : 1); ALLOC(h->d_cmo_xy, h->n_obs_local ? h->n_obs_local : 1);
+  ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_cfree, 9 * nc);
+  if (!dev_repack) { ALLOC(h->d_seg, segv.size()); ALLOC(h->d_slabB, (size_t)kK2W * segv.size()); }
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   h->d_S = nullptr; h->d_Linv = nullptr; h->d_dflag = nullptr; h->dense_N = 0;
@@ -1527,15 +1588,79 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   UP(h->d_pt_rng, pt_rng.data(), np);
   UP(h->d_wl, wlv.data(), wlv.size());
   UP(h->d_cam_active, P.cam_active.data(), nc);
-  UP(h->d_oxy, oxy.data(), 2 * ns);
   UP(h->d_giant, giant.data(), giant.size());
-  UP(h->d_seg, segv.data(), segv.size());
-  UP(h->d_cmo_pt, cmo_pt.data(), (size_t)h->n_obs_local);
-  UP(h->d_cmo_xy, cmo_xy.data(), (size_t)h->n_obs_local);
-  UP(h->d_cam_seg_off, cam_seg_off.data(), nc + 1);
+  if (!dev_repack) {
+    UP(h->d_oxy, oxy.data(), 2 * ns);
+    UP(h->d_seg, segv.data(), segv.size());
+    UP(h->d_cmo_pt, cmo_pt.data(), (size_t)h->n_obs_local);
+    UP(h->d_cmo_xy, cmo_xy.data(), (size_t)h->n_obs_local);
+    UP(h->d_cam_seg_off, cam_seg_off.data(), nc + 1);
+  }
+  lap("alloc + upload");
+  if (dev_repack) {
+    // Measurement arrays on the device: the caller's observations go up once as they are; oxy is gathered
+    // through slot_orig, the camera-major copy is a radix sort of (camera, slot) keys.  Same arrays as the host path builds.
+    rc = MIBA_OK;
+    double2* d_obs = nullptr; int32_t* d_ocam_in = nullptr; int64_t* d_so = nullptr; double2* d_pp = nullptr;
+    uint64_t *k0 = nullptr, *k1 = nullptr; uint32_t *v0 = nullptr, *v1 = nullptr; int32_t *d_cnt = nullptr, *d_spt = nullptr;
+    auto tmp_free = [&]() {
+      (void)hipFree(d_obs); (void)hipFree(d_ocam_in); (void)hipFree(d_so); (void)hipFree(d_pp); (void)hipFree(k0); (void)hipFree(k1);
+      (void)hipFree(v0); (void)hipFree(v1); (void)hipFree(d_cnt); (void)hipFree(d_spt);
+    };
+    const size_t no = (size_t)(p->n_obs ? p->n_obs : 1), ns1 = ns ? ns : 1;
+    hipError_t e = hipMalloc(&d_obs, no * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&d_so, ns1 * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&k0, ns1 * 8);
+    if (e == hipSuccess) e = hipMalloc(&k1, ns1 * 8);
+    if (e == hipSuccess) e = hipMalloc(&v0, ns1 * 4);
+    if (e == hipSuccess) e = hipMalloc(&v1, ns1 * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_cnt, (nc + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_spt, ns1 * sizeof(int32_t));
+    if (e == hipSuccess && h->cam_model) {
+      e = hipMalloc(&d_ocam_in, no * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMalloc(&d_pp, nc * sizeof(double2));
+      if (e == hipSuccess) e = hipMemcpyAsync(d_ocam_in, p->obs_cam, (size_t)p->n_obs * sizeof(int32_t), hipMemcpyHostToDevice, h->st);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_pp, h->principal.data(), nc * sizeof(double2), hipMemcpyHostToDevice, h->st);
+    }
+    if (e == hipSuccess && p->n_obs) e = hipMemcpyAsync(d_obs, p->obs_xy, (size_t)p->n_obs * sizeof(double2), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess && ns) e = hipMemcpyAsync(d_so, P.slot_orig.data() + h->slot_base, ns * sizeof(int64_t), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (nc + 1) * sizeof(int32_t), h->st);
+    std::vector<int32_t> cnt(nc + 1, 0);
+    if (e == hipSuccess && ns) {
+      hipLaunchKernelGGL(k_gather_oxy, dim3(nblk(ns, 256)), dim3(256), 0, h->st, (int64_t)ns, (const int64_t*)d_so, (const double2*)d_obs,
+                         (const int32_t*)d_ocam_in, (const double2*)d_pp, h->d_oxy);
+      hipLaunchKernelGGL(k_slot_point, dim3(nblk(np, 256)), dim3(256), 0, h->st, (int32_t)np, (const int2*)h->d_pt_rng, d_spt);
+      hipLaunchKernelGGL(k_cmo_keys, dim3(nblk(ns, 256)), dim3(256), 0, h->st, (int64_t)ns, (const int32_t*)h->d_idx, (const int32_t*)h->d_ocam, k0, v0,
+                         d_cnt);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = device_sort_pairs(k0, k1, v0, v1, ns, 64, h->st);
+      if (e == hipSuccess && h->n_obs_local) {
+        hipLaunchKernelGGL(k_cmo_fill, dim3(nblk((size_t)h->n_obs_local, 256)), dim3(256), 0, h->st, h->n_obs_local, (const uint32_t*)v1,
+                           (const int32_t*)d_spt, (const double*)h->d_oxy, h->d_cmo_pt, h->d_cmo_xy);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, (nc + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, h->st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    tmp_free();
+    if (e != hipSuccess) { free_problem(h); return fail(h, MIBA_ERR_HIP, "device repack failed: %s", hipGetErrorString(e)); }
+    // segments of at most kSegObs observations of one camera
+    int64_t first = 0;
+    for (size_t c = 0; c < nc; ++c) {
+      cam_seg_off[c] = (int32_t)segv.size();
+      for (int64_t a = 0; a < cnt[c]; a += kSegObs)
+        segv.push_back(make_int4((int)c, (int)(first + a), (int)std::min<int64_t>(kSegObs, cnt[c] - a), 0));
+      first += cnt[c];
+    }
+    cam_seg_off[nc] = (int32_t)segv.size();
+    h->n_seg = (int32_t)segv.size();
+    ALLOC(h->d_seg, segv.size()); ALLOC(h->d_slabB, (size_t)kK2W * segv.size());
+    UP(h->d_seg, segv.data(), segv.size());
+    UP(h->d_cam_seg_off, cam_seg_off.data(), nc + 1);
+    lap("device repack (oxy, camera-major copy)");
+  }
 #undef ALLOC
 #undef UP
-  lap("alloc + upload");
   hipLaunchKernelGGL(k_fill, dim3(nblk(9 * nc, 256)), dim3(256), 0, h->st, 9 * nc, 1.0, h->d_cfree);   // all blocks free
 
   HIPCHK(h, hipMemsetAsync(h->d_sum, 0, S_COUNT * sizeof(double), h->st));
@@ -1563,7 +1688,10 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
     // one plan for all ranks, built once
     auto P = std::make_shared<Plan>();
     const char* po = getenv("MIBA_POINT_ORDER");
-    const int prc = build_plan(*P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->owned->n, po ? atoi(po) : 1);
+    DeviceSortCtx sort_ctx{h->owned->sub[0]->device, h->owned->sub[0]->st};
+    const PlanSorter sorter{device_plan_sort, &sort_ctx};
+    const int prc = build_plan(*P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, h->owned->n, po ? atoi(po) : 1,
+                               device_repack_wanted() ? &sorter : nullptr);
     if (prc) return fail(h, prc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", prc);
     const int rc = group_run(h, [&](miba_handle s, int) { return set_problem_impl(s, p, P); });
     std::vector<int32_t>().swap(P->idx);

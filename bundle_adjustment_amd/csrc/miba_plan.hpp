@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <chrono>
 #include <cstdio>
@@ -24,12 +25,13 @@ namespace miba {
 
 // fn(begin, end) over [0, n) on up to 16 host threads (MIBA_PLAN_THREADS overrides); ranges are disjoint
 template <typename F>
-inline void plan_parallel_for(int64_t n, F fn) {
+inline void plan_parallel_for(int64_t n, F fn, int64_t min_parallel = (1 << 16)) {
   unsigned t = std::thread::hardware_concurrency();
   if (const char* e = getenv("MIBA_PLAN_THREADS")) t = (unsigned)atoi(e);
   if (t < 1) t = 1;
   if (t > 16) t = 16;
-  if (n < (1 << 16) || t == 1) { fn(0, n); return; }
+  if ((int64_t)t > n) t = (unsigned)std::max<int64_t>(1, n);
+  if (n <= min_parallel || t == 1) { fn(0, n); return; }
   std::vector<std::thread> th;
   for (unsigned k = 1; k < t; ++k) th.emplace_back(fn, n * k / t, n * (k + 1) / t);
   fn(0, n / t);
@@ -52,6 +54,7 @@ struct PlanLap {
 constexpr int kChunk = 256;        // observation slots per chunk = threads per block
 constexpr int kWave = 64;          // a point never straddles a 64-slot wavelet (one wavefront)
 constexpr int kMaxCamSlots = 64;   // distinct cameras per (non-giant) tile: LDS accumulator rows
+constexpr int kSpanSeg = 1 << 15;     // points per independently tiled segment of the point sequence
 constexpr int kMaxChunksPerTile = 8;   // default below 4 M observations (16 above); MIBA_TILE_CHUNKS overrides (1..16)
 constexpr int kJComp = 26;         // doubles stored per observation: F 18, E 6, r 2
 constexpr int kPtRec = 12;        // per-point record: X 0..2 | z = sp.(C^-1 g) 3..5 | W = diag(sp) C^-1 diag(sp) 6..11
@@ -94,9 +97,17 @@ struct Plan {
 };
 
 // point_order: 0 = caller's order, 1 = sort by smallest camera index (camera locality)
+// optional sorter of build_plan: fills obs_sorted[n_valid] with the indices of the valid observations ordered by
+// (sorted_of[obs_pt], obs_cam), stable; returns 0, or non-zero to make build_plan use its host sort
+struct PlanSorter {
+  int (*fn)(void* ctx, int64_t n_obs, int32_t n_pt, const int32_t* obs_cam, const int32_t* obs_pt, const uint8_t* ok,
+            const int32_t* sorted_of /*[n_pt]*/, int32_t n_act, int64_t n_valid, int64_t* obs_sorted);
+  void* ctx;
+};
+
 inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const int32_t* obs_cam,
                       const int32_t* obs_pt, const double* obs_xy, const double* X, int world_size,
-                      int point_order) {
+                      int point_order, const PlanSorter* sorter = nullptr) {
   PlanLap lap;
   P = Plan();
   P.n_cam = n_cam; P.n_pt_in = n_pt; P.n_obs_in = n_obs;
@@ -109,17 +120,33 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   std::vector<int32_t> mincam(n_pt, INT32_MAX);
   std::vector<uint8_t> ok(n_obs ? n_obs : 1, 0);
   P.cam_active.assign(n_cam, 0);
-  for (int64_t i = 0; i < n_obs; ++i) {
-    const int32_t p = obs_pt[i], c = obs_cam[i];
-    if (p == -1) continue;
-    if (p < 0 || p >= n_pt || c < 0 || c >= n_cam) return -1;
-    if (std::isnan(obs_xy[2 * i])) continue;
-    if (X && std::isnan(X[3 * (size_t)p])) continue;
-    ok[i] = 1;
-    cnt[p]++;
-    mincam[p] = std::min(mincam[p], c);
-    P.cam_active[c] = 1;
-    P.n_valid++;
+  {
+    // threaded over observation ranges; counts and minima per point through relaxed atomics (order-independent results)
+    std::vector<int64_t> n_ok(17, 0);
+    std::vector<int> bad(17, 0);
+    unsigned slot = 0;
+    std::mutex mu;
+    plan_parallel_for(n_obs, [&](int64_t a, int64_t b) {
+      unsigned me;
+      { std::lock_guard<std::mutex> lk(mu); me = slot++; }
+      int64_t nv = 0;
+      for (int64_t i = a; i < b; ++i) {
+        const int32_t p = obs_pt[i], c = obs_cam[i];
+        if (p == -1) continue;
+        if (p < 0 || p >= n_pt || c < 0 || c >= n_cam) { bad[me] = 1; return; }
+        if (std::isnan(obs_xy[2 * i])) continue;
+        if (X && std::isnan(X[3 * (size_t)p])) continue;
+        ok[i] = 1;
+        __atomic_fetch_add(&cnt[p], 1, __ATOMIC_RELAXED);
+        int32_t cur = __atomic_load_n(&mincam[p], __ATOMIC_RELAXED);
+        while (c < cur && !__atomic_compare_exchange_n(&mincam[p], &cur, c, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        __atomic_store_n(&P.cam_active[c], (uint8_t)1, __ATOMIC_RELAXED);
+        ++nv;
+      }
+      n_ok[me] = nv;
+    });
+    for (int v : bad) if (v) return -1;
+    for (int64_t v : n_ok) P.n_valid += v;
   }
   lap("filter");
   // Tile size: 16 chunks once that still leaves a thousand tiles (fewer tile prologues and less padding: 3.5 % on the
@@ -146,16 +173,26 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   // --- bucket observations by sorted point (stable: file order), then sort each by camera
   std::vector<int64_t> off(n_act + 1, 0);
   for (int32_t s = 0; s < n_act; ++s) off[s + 1] = off[s] + cnt[P.pt_orig[s]];
+  // observations of every sorted point, ascending camera, file order among equal cameras: a stable sort of the valid
+  // observations by (sorted point, camera).  On the GPU when the caller brings a sorter (miba_set_problem: rocPRIM radix
+  // sort), else bucket + per-point sort on the host threads; both give the same permutation.
   std::vector<int64_t> obs_sorted(P.n_valid ? P.n_valid : 1);
-  {
+  bool sorted_on_device = false;
+  if (sorter && sorter->fn && P.n_valid > 0)
+    sorted_on_device = sorter->fn(sorter->ctx, n_obs, n_pt, obs_cam, obs_pt, ok.data(), sorted_of.data(), n_act, P.n_valid, obs_sorted.data()) == 0;
+  if (!sorted_on_device) {
     std::vector<int64_t> cur(off.begin(), off.end() - 1);
     for (int64_t i = 0; i < n_obs; ++i)
       if (ok[i]) obs_sorted[cur[sorted_of[obs_pt[i]]]++] = i;
+    plan_parallel_for(n_act, [&](int64_t s0, int64_t s1) {
+      for (int64_t s = s0; s < s1; ++s)
+        std::stable_sort(obs_sorted.begin() + off[s], obs_sorted.begin() + off[s + 1],
+                         [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
+    });
   }
-  plan_parallel_for(n_act, [&](int64_t s0, int64_t s1) {
-    for (int64_t s = s0; s < s1; ++s)
-      std::stable_sort(obs_sorted.begin() + off[s], obs_sorted.begin() + off[s + 1],
-                       [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
+  std::vector<int32_t> sorted_cam(P.n_valid ? P.n_valid : 1);
+  plan_parallel_for(P.n_valid, [&](int64_t a, int64_t b) {
+    for (int64_t j = a; j < b; ++j) sorted_cam[j] = obs_cam[obs_sorted[j]];
   });
   lap("bucket + per-point sort");
   // --- tiling, phase 1: cut the point sequence into tiles.  A tile holds whole points, at most kMaxCamSlots
@@ -164,44 +201,57 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   struct Span { int32_t s0, s1, giant; };
   std::vector<Span> spans;
   {
-    std::vector<int32_t> stamp(n_cam, -1);
+    // The point sequence is cut into segments of kSpanSeg points that are tiled independently (a tile never crosses a
+    // segment boundary: under 2 % more tiles at Final-13682), so the greedy walk, which carries the open tile's camera set
+    // from point to point, runs on worker threads; the result does not depend on their number.
     const int64_t cap = (int64_t)max_chunks * kChunk - (max_chunks > 1 ? kWave : 0);
-    int32_t open_s0 = -1, ncs = 0, span_id = 0;
-    int64_t used = 0;
-    auto close = [&](int32_t s_end) {
-      if (open_s0 >= 0) spans.push_back(Span{open_s0, s_end, 0});
-      open_s0 = -1;
-    };
-    for (int32_t s = 0; s < n_act; ++s) {
-      const int64_t a = off[s], b = off[s + 1];
-      const int32_t L = (int32_t)(b - a);
-      if (L > kWave) {
-        close(s);
-        spans.push_back(Span{s, s + 1, 1});
-        continue;
-      }
-      auto count_new = [&]() {
-        int add = 0;
-        int32_t prev = -1;
-        for (int64_t j = a; j < b; ++j) {
-          const int32_t c = obs_cam[obs_sorted[j]];
-          if (c != prev && stamp[c] != span_id) ++add;
-          prev = c;
-        }
-        return add;
+    const int32_t n_seg = (n_act + kSpanSeg - 1) / kSpanSeg;
+    std::vector<std::vector<Span>> seg_spans((size_t)n_seg);
+    auto tile_segment = [&](int32_t sg, std::vector<int32_t>& stamp, int32_t& span_id) {
+      std::vector<Span>& out = seg_spans[(size_t)sg];
+      const int32_t s_begin = sg * kSpanSeg, s_stop = std::min(n_act, s_begin + kSpanSeg);
+      int32_t open_s0 = -1, ncs = 0;
+      int64_t used = 0;
+      auto close = [&](int32_t s_end) {
+        if (open_s0 >= 0) out.push_back(Span{open_s0, s_end, 0});
+        open_s0 = -1;
       };
-      if (open_s0 >= 0) {
-        const int add = count_new();
-        if (ncs + add > kMaxCamSlots || used + L > cap) close(s);
+      for (int32_t s = s_begin; s < s_stop; ++s) {
+        const int64_t a = off[s], b = off[s + 1];
+        const int32_t L = (int32_t)(b - a);
+        if (L > kWave) {
+          close(s);
+          out.push_back(Span{s, s + 1, 1});
+          continue;
+        }
+        if (open_s0 >= 0) {
+          int add = 0;
+          int32_t prev = -1;
+          for (int64_t j = a; j < b; ++j) {
+            const int32_t c = sorted_cam[j];
+            if (c != prev && stamp[c] != span_id) ++add;
+            prev = c;
+          }
+          if (ncs + add > kMaxCamSlots || used + L > cap) close(s);
+        }
+        if (open_s0 < 0) { open_s0 = s; ++span_id; ncs = 0; used = 0; }
+        for (int64_t j = a; j < b; ++j) {
+          const int32_t c = sorted_cam[j];
+          if (stamp[c] != span_id) { stamp[c] = span_id; ++ncs; }
+        }
+        used += L;
       }
-      if (open_s0 < 0) { open_s0 = s; ++span_id; ncs = 0; used = 0; }
-      for (int64_t j = a; j < b; ++j) {
-        const int32_t c = obs_cam[obs_sorted[j]];
-        if (stamp[c] != span_id) { stamp[c] = span_id; ++ncs; }
-      }
-      used += L;
-    }
-    close(n_act);
+      close(s_stop);
+    };
+    plan_parallel_for(n_seg, [&](int64_t g0, int64_t g1) {
+      std::vector<int32_t> stamp(n_cam, -1);
+      int32_t span_id = 0;
+      for (int64_t sg = g0; sg < g1; ++sg) tile_segment((int32_t)sg, stamp, span_id);
+    }, 1);
+    size_t total = 0;
+    for (auto& v : seg_spans) total += v.size();
+    spans.reserve(total);
+    for (auto& v : seg_spans) spans.insert(spans.end(), v.begin(), v.end());
   }
   lap("phase 1 (tile spans)");
   // --- phase 2: lay every tile out.  Inside a tile the point order is free, so its points are packed
@@ -223,6 +273,16 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     std::vector<int32_t> order, bin_free;
     std::vector<std::vector<int32_t>> bins;
     int64_t& slots = Q.slots;
+    if (t_begin < t_end) {
+      // capacity up front (observations of the range + padding): the arrays grow by push_back, without reallocation copies
+      const int64_t n_obs_rng = off[spans[t_end - 1].s1] - off[spans[t_begin].s0];
+      const size_t est = (size_t)(n_obs_rng + n_obs_rng / 16 + (int64_t)(t_end - t_begin) * kChunk + 4096);
+      const size_t n_pts_rng = (size_t)(spans[t_end - 1].s1 - spans[t_begin].s0);
+      Q.idx.reserve(est); Q.ocam.reserve(est); Q.slot_orig.reserve(est);
+      Q.new_orig.reserve(n_pts_rng); Q.pt_first.reserve(n_pts_rng); Q.pt_count.reserve(n_pts_rng);
+      Q.tiles.reserve(t_end - t_begin); Q.tile_cams.reserve((t_end - t_begin) * (size_t)kMaxCamSlots);
+      Q.groups.reserve(est / kChunk + (t_end - t_begin));
+    }
     auto pad_to = [&](int64_t mult) {
       while (slots % mult) { Q.idx.push_back(-1); Q.ocam.push_back(0); Q.slot_orig.push_back(-1); ++slots; }
     };

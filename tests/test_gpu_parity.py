@@ -342,3 +342,42 @@ def test_constant_blocks_match_golden_and_oracle(oracle, name):
     for a, b in zip(its2, oits):
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
         assert a["linear_solver_iterations"] == b["linear_solver_iterations"]
+
+
+def test_device_repack_equals_host_repack():
+    """miba_set_problem sorts the observations and builds the measurement arrays on the GPU (rocPRIM radix sorts, gather
+    kernels; MIBA_DEVICE_PLAN=1, the default) or on the host threads (=0).  Both must give the same layout: every result
+    that depends on the order of summation is then bit-identical.  Shuffled file order, filtered observations (point -1,
+    NaN measurement), a duplicated observation and a giant point."""
+    rng = np.random.default_rng(77)
+    pr = synth.make_problem(90, 7000, 33000, seed=41, shuffle_obs=True)
+    cams0, pts0 = synth.perturb(pr, 0.004, 0.05, seed=42)
+    oc, op, oxy = pr["obs_cam"].copy(), pr["obs_pt"].copy(), pr["obs_xy"].copy()
+    op[rng.choice(op.size, 200, replace=False)] = -1
+    oxy[rng.choice(op.size, 150, replace=False), 0] = np.nan
+    oc = np.concatenate([oc, oc[5:6], np.arange(90, dtype=np.int32)]); op = np.concatenate([op, op[5:6], np.full(90, 17, np.int32)])
+    xy17, z = synth.project(pr["cams"], pr["pts"], np.arange(90), np.full(90, 17))
+    oxy = np.concatenate([oxy, oxy[5:6], np.where((z < 0)[:, None], xy17, np.nan)])
+    probe = rng.normal(size=(90, 9))
+    res = []
+    for mode in ("0", "1"):
+        os.environ["MIBA_DEVICE_PLAN"] = mode
+        try:
+            s = miba.Solver(device_id=0)
+            s.set_problem(cams0, pts0, oc, op, oxy)
+        finally:
+            os.environ.pop("MIBA_DEVICE_PLAN", None)
+        ev = s.evaluate(jac=True, grad=True)
+        ls = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR), probe=probe)
+        its, summ = s.solve(miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, max_num_iterations=4))
+        s.close()
+        res.append((ev, ls, its, summ))
+    (e0, l0, i0, s0), (e1, l1, i1, s1) = res
+    assert s0["num_residual_blocks"] == s1["num_residual_blocks"] and s0["num_residual_blocks"] < oc.size
+    for k in ("r", "Jc", "Jp", "grad_cam", "grad_pt"):
+        assert np.array_equal(e0[k], e1[k]), k
+    assert np.array_equal(l0["rhs"], l1["rhs"])   # camera-major pass: sums in the order of the camera-major copy
+    for k in ("Sv", "y_cam", "y_pt"):             # the product adds through LDS atomics: last-bit noise from run to run
+        assert rel(l0[k], l1[k]) <= 1e-11, k
+    assert l0["n_cg"] == l1["n_cg"]
+    assert np.abs(np.array([r["cost"] for r in i0]) - np.array([r["cost"] for r in i1])).max() <= 1e-10 * i0[0]["cost"]
