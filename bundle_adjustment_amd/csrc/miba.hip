@@ -27,6 +27,7 @@
 #include "miba_kernels.hpp"
 #include "miba_mf.hpp"
 #include "miba_dense.hpp"
+#include "miba_sparse.hpp"
 #include "miba_plan.hpp"
 #include "miba_comm.hpp"
 #include "miba_sort.hpp"
@@ -182,7 +183,16 @@ struct miba_handle_s {
   int dense_N = 0;
   double* d_camacc2 = nullptr;   // SCHUR_JACOBI: per-camera sum G'WG [n_cam][64], allocated on first use
   int4* d_dseg = nullptr; int32_t* d_dpts = nullptr; int32_t n_dseg = 0;   // planned assembly: block segments, their points
-  bool dense_planned = false;
+  bool dense_planned = false, dense_plan_tried = false;
+  // tile-sparse exact solve (miba_sparse.hpp), built on first use: tiles of the lower block triangle of S + the right-hand-side
+  // tile row, tile map, ordering (pos: camera group -> tile row, grp: its inverse), per-column and per-row tile lists
+  int sparse_state = 0;            // 0 not tried, 1 ready, -1 the pattern does not fit (PCG to eta_exact stands in)
+  int sp_nT = 0;
+  int64_t sp_n_mat = 0;            // tiles of the matrix; the right-hand-side tiles follow them
+  double *d_sp_tiles = nullptr, *d_sp_Ldiag = nullptr, *d_sp_y = nullptr, *d_sp_x = nullptr;
+  int32_t *d_sp_map = nullptr, *d_sp_pos = nullptr, *d_sp_grp = nullptr;
+  int32_t *d_sp_col_rows = nullptr, *d_sp_col_slots = nullptr, *d_sp_row_cols = nullptr, *d_sp_row_slots = nullptr;
+  std::vector<int64_t> sp_col_ptr, sp_row_ptr;
   double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
   double *d_sum = nullptr, *d_max = nullptr;   // [S_COUNT] each
   Ctl* d_ctl = nullptr;
@@ -774,15 +784,31 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
 }
 
 
-// ---- exact reduced solve (non-iterative linear_solver_type, few cameras) --------------------
-// Used when the options ask for a factorisation-based solver, the matrix-free kernels are active and
-// N = 9 n_cam (rounded up to 64) <= kDenseMaxN; MIBA_DENSE=0 keeps the PCG-to-eta_exact stand-in.
-bool dense_wanted(miba_handle h, const miba_options* o) {
-  if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR || !h->use_mf) return false;
+// ---- exact reduced solve (non-iterative linear_solver_type) ---------------------------------
+// Used when the options ask for a factorisation-based solver and the matrix-free kernels are active:
+//   kExactDense   N = 9 n_cam (rounded up to 64) <= kDenseMaxN: dense S, blocked Cholesky (miba_dense.hpp)
+//   kExactSparse  beyond that: S as 64 x 64 tiles where cameras share points plus fill (miba_sparse.hpp), if the pattern fits
+//   kExactNone    otherwise, or with MIBA_DENSE=0 / MIBA_EXACT=pcg: PCG to eta_exact stands in
+// MIBA_EXACT=dense|sparse|pcg overrides the choice by size (tests).
+enum { kExactNone = 0, kExactDense = 1, kExactSparse = 2 };
+int sparse_symbolic(miba_handle h);
+int exact_kind(miba_handle h, const miba_options* o, int* kind) {
+  *kind = kExactNone;
+  if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR || !h->use_mf) return MIBA_OK;
   const char* e = getenv("MIBA_DENSE");
-  if (e && atoi(e) == 0) return false;
+  if (e && atoi(e) == 0) return MIBA_OK;
+  const char* x = getenv("MIBA_EXACT");
+  if (x && !strcmp(x, "pcg")) return MIBA_OK;
   const size_t N = (9 * (size_t)h->n_cam + kNB - 1) / kNB * kNB;
-  return N <= (size_t)kDenseMaxN;
+  const bool fits_dense = N <= (size_t)kDenseMaxN;
+  if (fits_dense && !(x && !strcmp(x, "sparse"))) { *kind = kExactDense; return MIBA_OK; }
+  if (x && !strcmp(x, "dense")) return MIBA_OK;
+  if (h->sparse_state == 0) {
+    const int rc = sparse_symbolic(h);
+    if (rc) return rc;
+  }
+  if (h->sparse_state > 0) *kind = kExactSparse;
+  return MIBA_OK;
 }
 
 
@@ -793,10 +819,11 @@ bool dense_wanted(miba_handle h, const miba_options* o) {
 constexpr int64_t kDensePlanMax = (int64_t)1 << 28;
 int dense_plan(miba_handle h) {
   h->dense_planned = false;
+  h->dense_plan_tried = true;
   if (const char* e = getenv("MIBA_DENSE_PLAN")) if (atoi(e) == 0) return MIBA_OK;
   const Plan& P = h->plan_ref();
   const int32_t nc = h->n_cam;
-  if (nc > 4096) return MIBA_OK;
+  if (nc > 20000) return MIBA_OK;   // the block directory below is dense in camera pairs: 1.6 GB of host memory at this bound
   const size_t nkey = (size_t)nc * (nc + 1) / 2;
   // the host copy of the per-slot camera ids was released after the upload: read the shard's back
   std::vector<int32_t> ocam((size_t)(h->n_slots ? h->n_slots : 1));
@@ -812,17 +839,19 @@ int dense_plan(miba_handle h) {
         if (c[a] >= c[b]) { first[key_of(c[a], c[b]) + 1]++; ++total; }
     if (total > kDensePlanMax) return MIBA_OK;
   }
-  for (size_t k = 0; k < nkey; ++k) first[k + 1] += first[k];
-  std::vector<int32_t> pts((size_t)(total ? total : 1));
+  // first[k + 1] = start of block k while the instances are filled in (it is block k's cursor, and ends at the block's end, which
+  // is block k + 1's start): afterwards first[] is the usual directory, without a second array of this size
   {
-    std::vector<int64_t> cur(first.begin(), first.end() - 1);
-    for (int32_t q = 0; q < h->n_pt; ++q) {
-      const int32_t* c = ocam.data() + (P.pt_first[h->pt_base + q] - h->slot_base);
-      const int32_t L = P.pt_count[h->pt_base + q];
-      for (int32_t a = 0; a < L; ++a)
-        for (int32_t b = 0; b < L; ++b)
-          if (c[a] >= c[b]) pts[(size_t)cur[key_of(c[a], c[b])]++] = q;
-    }
+    int64_t run = 0;
+    for (size_t k = 0; k < nkey; ++k) { const int64_t c = first[k + 1]; first[k + 1] = run; run += c; }
+  }
+  std::vector<int32_t> pts((size_t)(total ? total : 1));
+  for (int32_t q = 0; q < h->n_pt; ++q) {
+    const int32_t* c = ocam.data() + (P.pt_first[h->pt_base + q] - h->slot_base);
+    const int32_t L = P.pt_count[h->pt_base + q];
+    for (int32_t a = 0; a < L; ++a)
+      for (int32_t b = 0; b < L; ++b)
+        if (c[a] >= c[b]) pts[(size_t)first[key_of(c[a], c[b]) + 1]++] = q;
   }
   std::vector<int4> segs;
   for (int32_t ci = 0; ci < nc; ++ci)
@@ -830,7 +859,7 @@ int dense_plan(miba_handle h) {
       const size_t k = key_of(ci, cj);
       const int64_t n = first[k + 1] - first[k];
       for (int64_t o = 0; o < n; o += kDenseSeg)
-        segs.push_back(make_int4(ci | (cj << 12), (int)(first[k] + o), (int)std::min<int64_t>(kDenseSeg, n - o), n > kDenseSeg ? 1 : 0));
+        segs.push_back(make_int4(ci, (int)(first[k] + o), (int)std::min<int64_t>(kDenseSeg, n - o), cj | ((n > kDenseSeg ? 1 : 0) << 30)));
     }
   int rc = dev_alloc(h, &h->d_dseg, segs.size());
   if (rc) return rc;
@@ -853,25 +882,23 @@ int ensure_dense(miba_handle h) {
   rc = dev_alloc(h, &h->d_dflag, 1);
   if (rc) return rc;
   h->dense_N = (int)N;
-  return dense_plan(h);
+  return h->dense_plan_tried ? MIBA_OK : dense_plan(h);
 }
 
-// S (lower triangle, row-major [N][N]) of the current Schur init: point pairs, all-reduce, block diagonal
-int dense_assemble(miba_handle h) {
-  int rc = ensure_dense(h);
-  if (rc) return rc;
-  const int N = h->dense_N;
-  HIPCHK(h, hipMemsetAsync(h->d_S, 0, ((size_t)N + kNB) * N * sizeof(double), h->st));
+// S of the current Schur init into the storage D names (dense lower triangle, or tiles): cleared, point pairs, all-reduce over
+// the first n_reduce doubles, block diagonal
+int reduced_assemble(miba_handle h, const SDst D, size_t n_clear, size_t n_reduce) {
+  HIPCHK(h, hipMemsetAsync(D.S, 0, n_clear * sizeof(double), h->st));
   const bool loss = h->loss.type != kLossNone;   // the planned instance lists name no slots, the loss weights are per slot
   if (h->dense_planned && !loss) {
     if (h->n_dseg)
       hipLaunchKernelGGL(k_dense_blocks, dim3(nblk(h->n_dseg, 4)), dim3(256), 0, h->st, h->n_dseg, h->d_dseg, h->d_dpts, h->d_ct, h->d_cm,
-                         h->d_sc, h->d_ptrec, h->d_S, N);
+                         h->d_sc, h->d_ptrec, D);
   } else if (h->n_tiles) {
 #define MIBA_PAIRS_ARGS dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_tile_cams, h->d_ct, h->d_cm, \
-                        h->d_sc, h->d_ptrec, (const double*)h->d_omega, h->d_S, N
+                        h->d_sc, h->d_ptrec, (const double*)h->d_omega, D
 #define MIBA_GIANT_ARGS dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, h->d_tiles, h->d_giant, h->d_grps, h->d_idx, h->d_ocam, h->d_ct, \
-                        h->d_cm, h->d_sc, h->d_ptrec, (const double*)h->d_omega, h->d_S, N
+                        h->d_cm, h->d_sc, h->d_ptrec, (const double*)h->d_omega, D
     if (loss) {
       hipLaunchKernelGGL(k_dense_pairs<true>, MIBA_PAIRS_ARGS);
       if (h->n_giant) hipLaunchKernelGGL(k_dense_pairs_giant<true>, MIBA_GIANT_ARGS);
@@ -883,11 +910,19 @@ int dense_assemble(miba_handle h) {
 #undef MIBA_GIANT_ARGS
   }
   HIPCHK(h, hipGetLastError());
-  rc = allreduce(h, h->d_S, (size_t)N * N, ncclSum);
+  const int rc = allreduce(h, D.S, n_reduce, ncclSum);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_dense_diag, dim3(nblk(81 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, h->d_camacc, h->d_Dc2, h->d_S, N);
+  hipLaunchKernelGGL(k_dense_diag, dim3(nblk(81 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, h->d_camacc, h->d_Dc2, D);
   HIPCHK(h, hipGetLastError());
   return MIBA_OK;
+}
+
+// S (lower triangle, row-major [N][N]) of the current Schur init
+int dense_assemble(miba_handle h) {
+  int rc = ensure_dense(h);
+  if (rc) return rc;
+  const int N = h->dense_N;
+  return reduced_assemble(h, SDst{h->d_S, N, nullptr, nullptr, 0}, ((size_t)N + kNB) * N, (size_t)N * N);
 }
 
 // blocked Cholesky of the lower triangle of A ([N + 64][N], N a multiple of 64, rows N.. zero) and the solve
@@ -934,11 +969,236 @@ int dense_solve(miba_handle h, int* status) {
   return dense_factor_solve(h, h->d_S, h->dense_N, h->d_Linv, h->d_rhs, 9 * h->n_cam, h->d_px, 9 * h->n_cam, h->d_dflag, status);
 }
 
+// ---- tile-sparse exact solve ------------------------------------------------------------------
+// Symbolic phase, once per problem, on the host: which 64 x 64 tiles of S (tile row = kTileCams consecutive cameras) hold
+// an entry, a minimum-degree elimination order of the tile rows, the fill that order produces, and the tile lists the numeric
+// kernels walk.  With several ranks every rank sees only its points: the tile graphs are united by a sum all-reduce of the
+// adjacency bits, 13 bits to a double, one hexadecimal digit per bit (up to 15 ranks cannot carry).
+int sparse_symbolic(miba_handle h) {
+  h->sparse_state = -1;
+  const Plan& P = h->plan_ref();
+  const int nT = (h->n_cam + kTileCams - 1) / kTileCams;
+  const size_t nW = ((size_t)nT + 63) / 64;
+  if (nT < 1 || nT > 32768 || h->cfg.world_size > 15) return MIBA_OK;
+  std::vector<uint64_t> adj((size_t)nT * nW, 0);
+  // memory the tiles may take: half of what is free now (the dense assembly plan and the lists need room too); with several
+  // ranks the smallest figure, so that every rank takes the same decision
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+  double free_all = (double)free_b;
+  {
+    std::vector<int32_t> ocam((size_t)(h->n_slots ? h->n_slots : 1));
+    if (h->n_slots) HIPCHK(h, hipMemcpy(ocam.data(), h->d_ocam, (size_t)h->n_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> g;
+    std::vector<uint64_t> mask(nW);
+    for (int32_t q = 0; q < h->n_pt; ++q) {
+      const int32_t* c = ocam.data() + (P.pt_first[h->pt_base + q] - h->slot_base);
+      const int32_t L = P.pt_count[h->pt_base + q];
+      g.clear();
+      for (int32_t a = 0; a < L; ++a) g.push_back(c[a] / kTileCams);
+      std::sort(g.begin(), g.end());
+      g.erase(std::unique(g.begin(), g.end()), g.end());
+      if (g.size() <= 32) {
+        for (size_t a = 0; a < g.size(); ++a)
+          for (size_t b2 = 0; b2 < g.size(); ++b2) adj[(size_t)g[a] * nW + (g[b2] >> 6)] |= (uint64_t)1 << (g[b2] & 63);
+      } else {
+        std::fill(mask.begin(), mask.end(), 0);
+        for (int32_t v : g) mask[v >> 6] |= (uint64_t)1 << (v & 63);
+        for (int32_t v : g)
+          for (size_t w = 0; w < nW; ++w) adj[(size_t)v * nW + w] |= mask[w];
+      }
+    }
+  }
+  if (multi_rank(h)) {
+    const size_t nd = adj.size() * 5;
+    std::vector<double> pk(nd);
+    for (size_t i = 0; i < adj.size(); ++i)
+      for (int k = 0; k < 5; ++k) {
+        uint64_t v = 0;
+        for (int j = 0; j < 13 && 13 * k + j < 64; ++j) v |= ((adj[i] >> (13 * k + j)) & 1) << (4 * j);
+        pk[5 * i + k] = (double)v;
+      }
+    double* d_pk = nullptr;
+    HIPCHK(h, hipMalloc(&d_pk, nd * sizeof(double)));
+    hipError_t e = hipMemcpy(d_pk, pk.data(), nd * sizeof(double), hipMemcpyHostToDevice);
+    int rc = (e == hipSuccess) ? allreduce(h, d_pk, nd, ncclSum) : fail(h, MIBA_ERR_HIP, "upload of the tile graph failed: %s", hipGetErrorString(e));
+    if (!rc) {
+      e = hipStreamSynchronize(h->st);
+      if (e == hipSuccess) e = hipMemcpy(pk.data(), d_pk, nd * sizeof(double), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = fail(h, MIBA_ERR_HIP, "download of the tile graph failed: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+      const double neg = -free_all;
+      e = hipMemcpy(d_pk, &neg, sizeof(double), hipMemcpyHostToDevice);
+      if (e == hipSuccess) rc = allreduce(h, d_pk, 1, ncclMax);
+      if (!rc && e == hipSuccess) e = hipStreamSynchronize(h->st);
+      double got = neg;
+      if (!rc && e == hipSuccess) e = hipMemcpy(&got, d_pk, sizeof(double), hipMemcpyDeviceToHost);
+      if (!rc && e != hipSuccess) rc = fail(h, MIBA_ERR_HIP, "exchange of the free memory failed: %s", hipGetErrorString(e));
+      free_all = -got;
+    }
+    (void)hipFree(d_pk);
+    if (rc) return rc;
+    for (size_t i = 0; i < adj.size(); ++i) {
+      uint64_t w = 0;
+      for (int k = 0; k < 5; ++k) {
+        const uint64_t v = (uint64_t)pk[5 * i + k];
+        for (int j = 0; j < 13 && 13 * k + j < 64; ++j)
+          if ((v >> (4 * j)) & 15) w |= (uint64_t)1 << (13 * k + j);
+      }
+      adj[i] = w;
+    }
+  }
+  for (int v = 0; v < nT; ++v) adj[(size_t)v * nW + (v >> 6)] &= ~((uint64_t)1 << (v & 63));
+
+  const int64_t max_tiles = (int64_t)(free_all / 2 / (4096 * sizeof(double)));
+
+  // minimum degree on the tile graph (ties: the lowest tile row, which keeps a banded problem banded)
+  auto popcnt_row = [&](int v) { int c = 0; for (size_t w = 0; w < nW; ++w) c += __builtin_popcountll(adj[(size_t)v * nW + w]); return c; };
+  std::vector<int32_t> deg(nT), pos(nT, -1), grp(nT);
+  for (int v = 0; v < nT; ++v) deg[v] = popcnt_row(v);
+  std::vector<std::vector<int32_t>> col_nodes(nT);
+  int64_t n_off = 0;
+  for (int k = 0; k < nT; ++k) {
+    int v = -1;
+    for (int u = 0; u < nT; ++u)
+      if (pos[u] < 0 && (v < 0 || deg[u] < deg[v])) v = u;
+    pos[v] = k;
+    grp[k] = v;
+    std::vector<int32_t>& nb = col_nodes[k];
+    const uint64_t* av = &adj[(size_t)v * nW];
+    for (size_t w = 0; w < nW; ++w)
+      for (uint64_t m = av[w]; m; m &= m - 1) nb.push_back((int32_t)(64 * w + __builtin_ctzll(m)));
+    n_off += (int64_t)nb.size();
+    if (2 * (int64_t)nT + n_off > max_tiles) return MIBA_OK;   // does not fit: sparse_state stays -1
+    for (int32_t u : nb) {
+      uint64_t* au = &adj[(size_t)u * nW];
+      for (size_t w = 0; w < nW; ++w) au[w] |= av[w];
+      au[v >> 6] &= ~((uint64_t)1 << (v & 63));
+      au[u >> 6] &= ~((uint64_t)1 << (u & 63));
+      deg[u] = popcnt_row(u);
+    }
+  }
+  std::vector<uint64_t>().swap(adj);
+
+  // slots: the diagonal tile of tile row p is slot p, the tiles below the diagonal follow column by column, then the
+  // right-hand-side tile of every column
+  const int64_t n_mat = nT + n_off;
+  std::vector<int32_t> map((size_t)(nT + 1) * nT, -1);
+  std::vector<int32_t> col_rows, col_slots;
+  std::vector<int64_t> col_ptr(nT + 1, 0);
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> row_list(nT);
+  col_rows.reserve((size_t)(n_mat + nT)); col_slots.reserve((size_t)(n_mat + nT));
+  int64_t next = nT;
+  for (int k = 0; k < nT; ++k) {
+    col_ptr[k] = (int64_t)col_rows.size();
+    std::vector<int32_t> rows;
+    for (int32_t u : col_nodes[k]) rows.push_back(pos[u]);
+    std::sort(rows.begin(), rows.end());
+    col_rows.push_back(k); col_slots.push_back(k);
+    map[(size_t)k * nT + k] = k;
+    for (int32_t r : rows) {
+      const int32_t slot = (int32_t)next++;
+      map[(size_t)r * nT + k] = slot;
+      col_rows.push_back(r); col_slots.push_back(slot);
+      row_list[r].push_back({k, slot});
+    }
+    col_rows.push_back(nT); col_slots.push_back((int32_t)(n_mat + k));
+    map[(size_t)nT * nT + k] = (int32_t)(n_mat + k);
+  }
+  col_ptr[nT] = (int64_t)col_rows.size();
+  std::vector<int32_t> row_cols, row_slots;
+  std::vector<int64_t> row_ptr(nT + 1, 0);
+  for (int r = 0; r < nT; ++r) {
+    row_ptr[r] = (int64_t)row_cols.size();
+    for (auto& e : row_list[r]) { row_cols.push_back(e.first); row_slots.push_back(e.second); }
+  }
+  row_ptr[nT] = (int64_t)row_cols.size();
+
+  int rc;
+#define SP_ALLOC(ptr, n) if ((rc = dev_alloc(h, &ptr, (size_t)(n)))) return rc
+  SP_ALLOC(h->d_sp_tiles, (size_t)(n_mat + nT) * 4096);
+  SP_ALLOC(h->d_sp_Ldiag, (size_t)nT * 4096);   // W = L^-T of every diagonal tile
+  SP_ALLOC(h->d_sp_y, (size_t)nT * 64);
+  SP_ALLOC(h->d_sp_x, (size_t)nT * 64);
+  SP_ALLOC(h->d_sp_map, map.size());
+  SP_ALLOC(h->d_sp_pos, nT);
+  SP_ALLOC(h->d_sp_grp, nT);
+  SP_ALLOC(h->d_sp_col_rows, col_rows.size());
+  SP_ALLOC(h->d_sp_col_slots, col_slots.size());
+  SP_ALLOC(h->d_sp_row_cols, row_cols.size());
+  SP_ALLOC(h->d_sp_row_slots, row_slots.size());
+#undef SP_ALLOC
+  if (!h->d_dflag && (rc = dev_alloc(h, &h->d_dflag, 1))) return rc;
+  if ((rc = upload(h, h->d_sp_map, map.data(), map.size()))) return rc;
+  if ((rc = upload(h, h->d_sp_pos, pos.data(), (size_t)nT))) return rc;
+  if ((rc = upload(h, h->d_sp_grp, grp.data(), (size_t)nT))) return rc;
+  if ((rc = upload(h, h->d_sp_col_rows, col_rows.data(), col_rows.size()))) return rc;
+  if ((rc = upload(h, h->d_sp_col_slots, col_slots.data(), col_slots.size()))) return rc;
+  if ((rc = upload(h, h->d_sp_row_cols, row_cols.data(), row_cols.size()))) return rc;
+  if ((rc = upload(h, h->d_sp_row_slots, row_slots.data(), row_slots.size()))) return rc;
+  h->sp_col_ptr.swap(col_ptr);
+  h->sp_row_ptr.swap(row_ptr);
+  h->sp_nT = nT;
+  h->sp_n_mat = n_mat;
+  if (!h->dense_plan_tried && (rc = dense_plan(h))) return rc;
+  h->sparse_state = 1;
+  return MIBA_OK;
+}
+
+// exact solution of S y = rhs into d_px through the tiles
+int sparse_solve(miba_handle h, int* status) {
+  const int nT = h->sp_nT;
+  const int64_t n_mat = h->sp_n_mat;
+  double* T = h->d_sp_tiles;
+  const SDst D{T, 0, h->d_sp_map, h->d_sp_pos, nT};
+  int rc = reduced_assemble(h, D, (size_t)(n_mat + nT) * 4096, (size_t)n_mat * 4096);
+  if (rc) return rc;
+  const int nb64 = nblk((size_t)nT * 64, 256);
+  hipLaunchKernelGGL(k_tchol_pad, dim3(nb64), dim3(256), 0, h->st, h->n_cam, nT, T, (const int32_t*)h->d_sp_grp);
+  hipLaunchKernelGGL(k_tchol_rhs, dim3(nb64), dim3(256), 0, h->st, h->n_cam, nT, (const double*)h->d_rhs, T, (int)n_mat, (const int32_t*)h->d_sp_grp);
+  HIPCHK(h, hipMemsetAsync(h->d_dflag, 0, sizeof(int32_t), h->st));
+  for (int k = 0; k < nT; ++k) {
+    const int64_t c0 = h->sp_col_ptr[k];
+    const int cnt = (int)(h->sp_col_ptr[k + 1] - c0);   // diagonal, tiles below it, right-hand side
+    hipLaunchKernelGGL(k_tchol_panel, dim3(cnt), dim3(kNB), 0, h->st, T, (const int32_t*)(h->d_sp_col_slots + c0), h->d_sp_Ldiag + (size_t)k * 4096,
+                       (int*)h->d_dflag);
+    const int m = cnt - 1;
+    if (m > 1)
+      hipLaunchKernelGGL(k_tchol_update, dim3(m, m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_rows + c0 + 1),
+                         (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const int32_t*)h->d_sp_map, nT);
+  }
+  hipLaunchKernelGGL(k_tchol_gety, dim3(nb64), dim3(256), 0, h->st, nT, (const double*)T, (int)n_mat, h->d_sp_y);
+  for (int k = nT - 1; k >= 0; --k) {
+    const int64_t r0 = h->sp_row_ptr[k];
+    const int nr = (int)(h->sp_row_ptr[k + 1] - r0);
+    hipLaunchKernelGGL(k_tchol_bwd, dim3(nr > 0 ? nr : 1), dim3(kNB), 0, h->st, (const double*)T, k, nr, (const int32_t*)(h->d_sp_row_cols + r0),
+                       (const int32_t*)(h->d_sp_row_slots + r0), (const double*)(h->d_sp_Ldiag + (size_t)k * 4096), h->d_sp_y, h->d_sp_x);
+  }
+  hipLaunchKernelGGL(k_tchol_unperm, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, (const double*)h->d_sp_x,
+                     (const int32_t*)h->d_sp_pos, h->d_px);
+  HIPCHK(h, hipGetLastError());
+  int32_t flag = 0;
+  HIPCHK(h, hipMemcpyAsync(&flag, h->d_dflag, sizeof(int32_t), hipMemcpyDeviceToHost, h->st));
+  if (h->d_ctl) HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));   // Schur-init failure flag
+  rc = sync_stream(h);
+  if (rc) return rc;
+  *status = flag ? 2 : 0;
+  return MIBA_OK;
+}
+
 // the linear solve of one LM iteration: exact factorisation where it applies, PCG otherwise
 int linear_solve(miba_handle h, const miba_options* o, int* n_it, int* status) {
-  if (dense_wanted(h, o)) {
+  int kind = kExactNone;
+  int rc = exact_kind(h, o, &kind);
+  if (rc) return rc;
+  if (kind == kExactDense) {
     *n_it = 1;
     return dense_solve(h, status);
+  }
+  if (kind == kExactSparse) {
+    *n_it = 1;
+    return sparse_solve(h, status);
   }
   const double q_tol = (o->linear_solver_type == MIBA_ITERATIVE_SCHUR) ? o->eta : o->eta_exact;
   return pcg_solve(h, q_tol, o->min_linear_solver_iterations, o->max_linear_solver_iterations, o->pcg_check_every, n_it, status);
@@ -1565,7 +1825,8 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   ALLOC(h->d_X, 3 * np); ALLOC(h->d_Xc, 3 * np); ALLOC(h->d_sp, 3 * np);
   h->d_J = nullptr;   // allocated on first use (ensure_J): the matrix-free LM loop never touches it
   h->d_S = nullptr; h->d_Linv = nullptr; h->d_dflag = nullptr; h->dense_N = 0;
-  h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false; h->d_camacc2 = nullptr;
+  h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false; h->dense_plan_tried = false; h->d_camacc2 = nullptr;
+  h->sparse_state = 0; h->d_sp_tiles = nullptr;
   h->d_omega = nullptr;
   ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
   // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
@@ -2125,10 +2386,15 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
   S.num_residual_blocks = (int32_t)std::min<int64_t>(h->n_valid_global, INT32_MAX);
   S.num_active_cameras = h->plan_ref().n_active_cam;
   S.num_active_points = (int32_t)h->plan_ref().pt_orig.size();
-  S.exact_linear_solver = dense_wanted(h, &o) ? 1 : 0;
   snprintf(S.message, sizeof(S.message), "Maximum number of iterations reached.");
   int rc = set_loss(h, &o);
   if (rc) return rc;
+  {
+    int kind = kExactNone;
+    rc = exact_kind(h, &o, &kind);   // (first use at this size: the symbolic phase of the tile-sparse factorisation)
+    if (rc) return rc;
+    S.exact_linear_solver = kind != kExactNone ? 1 : 0;
+  }
 
   // best-state buffers: d_cam_cand / d_Xc double as candidates, so keep the best state on the host side of
   // the swap: x (d_cam, d_X) is always the last ACCEPTED state, which in the monotonic algorithm is also

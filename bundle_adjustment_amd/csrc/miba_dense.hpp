@@ -19,6 +19,32 @@ constexpr int kDenseMaxN = 18432;   // 2048 cameras: S is 2.7 GB
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+// Where the assembly kernels put entry (a, b) of camera block (ci, cj) of S: a dense row-major matrix (N x N, map == nullptr), or
+// the 64 x 64 tiles of the tile-sparse factorisation (miba_sparse.hpp).  There a tile row holds kTileCams = 7 consecutive cameras
+// (63 rows and one padding row), the tile rows are permuted by the fill-reducing ordering (pos[group] = tile row), and
+// map[tile row * nT + tile column] is the tile's slot in S (lower block triangle only: a block whose tile row comes before its
+// tile column is written transposed; entries above the diagonal of a diagonal tile are dropped, the factorisation never reads them).
+constexpr int kTileCams = 7;
+struct SDst {
+  double* S;
+  int N;
+  const int32_t* map;
+  const int32_t* pos;
+  int nT;
+};
+__device__ __forceinline__ double* sdst_addr(const SDst D, int ci, int a, int cj, int b) {
+  if (!D.map) return D.S + (size_t)(9 * ci + a) * D.N + (9 * cj + b);
+  const int gi = ci / kTileCams, gj = cj / kTileCams;
+  int tr = D.pos[gi], tc = D.pos[gj];
+  int lr = 9 * (ci - kTileCams * gi) + a, lc = 9 * (cj - kTileCams * gj) + b;
+  if (tr < tc || (tr == tc && lr < lc)) {
+    if (ci == cj) return nullptr;
+    int t = tr; tr = tc; tc = t;
+    t = lr; lr = lc; lc = t;
+  }
+  return D.S + (size_t)D.map[(size_t)tr * D.nT + tc] * 4096 + (size_t)lr * 64 + lc;
+}
+
 // G = E' F_s (3x9, row a = point coordinate) of one observation and T = W G
 __device__ __forceinline__ void dense_obs_G(const double* cd, const double* s /*[9] camera scale*/, double x0, double x1, double x2,
                                             double* G) {
@@ -42,14 +68,14 @@ __device__ __forceinline__ void dense_WG(const double* W /*00 10 11 20 21 22*/, 
 }
 
 // S[cam_i block row][cam_j block column] -= T_i' G_j
-__device__ __forceinline__ void dense_sub_block(double* __restrict__ S, int N, int cam_i, int cam_j, const double* T, const double* Gj) {
-  double* dst = S + (size_t)(9 * cam_i) * N + 9 * cam_j;
+__device__ __forceinline__ void dense_sub_block(const SDst D, int cam_i, int cam_j, const double* T, const double* Gj) {
 #pragma unroll
   for (int a = 0; a < 9; ++a)
 #pragma unroll
     for (int b = 0; b < 9; ++b) {
       const double v = -(T[a] * Gj[b] + T[9 + a] * Gj[9 + b] + T[18 + a] * Gj[18 + b]);
-      atomicAdd(dst + (size_t)a * N + b, v);
+      double* dst = sdst_addr(D, cam_i, a, cam_j, b);
+      if (dst) atomicAdd(dst, v);
     }
 }
 
@@ -63,7 +89,7 @@ __global__ __launch_bounds__(256) void k_dense_pairs(const Tile* __restrict__ ti
                                                      const int2* __restrict__ wl, const int32_t* __restrict__ tile_cams,
                                                      const double* __restrict__ ct, const double* __restrict__ cm,
                                                      const double* __restrict__ sc, const double* __restrict__ ptrec,
-                                                     const double* __restrict__ omega, double* __restrict__ S, int N) {
+                                                     const double* __restrict__ omega, const SDst D) {
   __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
   __shared__ double s_sc[kMaxCamSlots * 9];
   __shared__ int s_id[kMaxCamSlots];
@@ -111,7 +137,7 @@ __global__ __launch_bounds__(256) void k_dense_pairs(const Tile* __restrict__ ti
 #pragma unroll
       for (int m = 0; m < 27; ++m) Gj[m] = lane_read(G[m], src);
       const int camj = __builtin_amdgcn_ds_bpermute(src, cam);
-      if (valid && d < cnt && cam >= camj) dense_sub_block(S, N, cam, camj, T, Gj);
+      if (valid && d < cnt && cam >= camj) dense_sub_block(D, cam, camj, T, Gj);
     }
   }
 }
@@ -123,7 +149,7 @@ __global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restric
                                                            const int32_t* __restrict__ ocam, const double* __restrict__ ct,
                                                            const double* __restrict__ cm, const double* __restrict__ sc,
                                                            const double* __restrict__ ptrec, const double* __restrict__ omega,
-                                                           double* __restrict__ S, int N) {
+                                                           const SDst D) {
   __shared__ double s_G[kChunk * 27];
   __shared__ int s_camj[kChunk];
   const Tile t = tiles[tile_list[blockIdx.x]];
@@ -181,7 +207,7 @@ __global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restric
           for (int j = 0; j < kChunk; ++j) {
             const int camj = s_camj[j];
             if (camj < 0 || cam_i < camj) continue;
-            dense_sub_block(S, N, cam_i, camj, T, s_G + 27 * j);
+            dense_sub_block(D, cam_i, camj, T, s_G + 27 * j);
           }
         }
       }
@@ -195,19 +221,19 @@ __global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restric
 // then a cross-lane reduction through LDS.  No atomics unless a block was cut into several segments
 // (seg.w = 1), so S is reproducible bit for bit for all but the very largest blocks.
 constexpr int kDenseSeg = 2048;
-__global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci | cj << 12, first, count, atomic}*/,
+__global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci, first, count, cj | atomic << 30}*/,
                                                       const int32_t* __restrict__ pts, const double* __restrict__ ct,
                                                       const double* __restrict__ cm, const double* __restrict__ sc,
-                                                      const double* __restrict__ ptrec, double* __restrict__ S, int N) {
+                                                      const double* __restrict__ ptrec, const SDst D) {
   __shared__ double s_red[4][64 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int sg = blockIdx.x * 4 + wv;
   if (sg >= n_seg) return;
   const int4 Sg = seg[sg];
-  const int key = __builtin_amdgcn_readfirstlane(Sg.x);
+  const int ci = __builtin_amdgcn_readfirstlane(Sg.x);
   const int first = __builtin_amdgcn_readfirstlane(Sg.y), n = __builtin_amdgcn_readfirstlane(Sg.z);
-  const int use_atomic = __builtin_amdgcn_readfirstlane(Sg.w);
-  const int ci = key & 0xFFF, cj = key >> 12;
+  const int w4 = __builtin_amdgcn_readfirstlane(Sg.w);
+  const int use_atomic = w4 >> 30, cj = w4 & 0x3FFFFFFF;
   double cdi[kCamLds], cdj[kCamLds], sci[9], scj[9];
   mf_stage_cam_init(cdi, ci, ct, cm);
   mf_stage_cam_init(cdj, cj, ct, cm);
@@ -237,7 +263,6 @@ __global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __r
   }
   double* sr = s_red[wv];
   const int sub = lane / 9, k9 = lane % 9;
-  double* dst = S + (size_t)(9 * ci) * N + 9 * cj;
 #pragma unroll
   for (int r = 0; r < 9; ++r) {   // block row r
 #pragma unroll
@@ -250,8 +275,11 @@ __global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __r
 #pragma unroll
     for (int s2 = 1; s2 < 7; ++s2) tot += __shfl(a, k9 + 9 * s2, 64);
     if (lane < 9) {
-      if (use_atomic) atomicAdd(dst + (size_t)r * N + lane, -tot);
-      else dst[(size_t)r * N + lane] = -tot;
+      double* dst = sdst_addr(D, ci, r, cj, lane);
+      if (dst) {
+        if (use_atomic) atomicAdd(dst, -tot);
+        else *dst = -tot;
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -329,18 +357,18 @@ __global__ __launch_bounds__(256) void k_mf_schurdiag(int n_seg, const int4* __r
 }
 
 // S += block diagonal B = F_s'F_s + D_c^2 (acc: upper triangle of F_s'F_s per camera), unit diagonal on the padding
-__global__ void k_dense_diag(int n_cam, const double* __restrict__ acc /*[n][64]*/, const double* __restrict__ Dc2,
-                             double* __restrict__ S, int N) {
+__global__ void k_dense_diag(int n_cam, const double* __restrict__ acc /*[n][64]*/, const double* __restrict__ Dc2, const SDst D) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 81 * (size_t)n_cam) {
     const int c = (int)(i / 81), a = (int)(i % 81) / 9, b = (int)(i % 9);
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     double v = acc[(size_t)kK2W * c + (9 * lo - (lo * (lo - 1)) / 2 + (hi - lo))];
     if (a == b) v += Dc2[9 * (size_t)c + a];
-    S[(size_t)(9 * c + a) * N + 9 * c + b] += v;
+    double* dst = sdst_addr(D, c, a, c, b);
+    if (dst) *dst += v;
   }
   const size_t r = 9 * (size_t)n_cam + i;
-  if (r < (size_t)N) S[r * N + r] = 1.0;
+  if (!D.map && r < (size_t)D.N) D.S[r * D.N + r] = 1.0;   // (the tiles set their own padding: k_tchol_pad)
 }
 
 // ---- blocked Cholesky, lower, right-looking --------------------------------------------------
@@ -361,9 +389,10 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {   // src_
 // factor goes to LDS as soon as it exists (Lt[j][r] = L[r][j]) and is read back as wave-uniform operands
 // for the rank-1 update (LDS operations of one wave execute in order: no barrier).  Lr = 1 / diagonal.
 // Returns true if a pivot was not positive.
-__device__ __forceinline__ bool chol_diag_wave(const double* __restrict__ S, int N, int k0, int lane, double* Lt, double* Lr) {
+__device__ __forceinline__ bool chol_diag_wave(const double* __restrict__ diag /*top-left entry of the block*/, size_t stride, int lane,
+                                               double* Lt, double* Lr) {
   double a[kNB];
-  const double* row = S + (size_t)(k0 + lane) * N + k0;
+  const double* row = diag + (size_t)lane * stride;
 #pragma unroll
   for (int c = 0; c < kNB; ++c) a[c] = row[c];
 #pragma unroll
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ S, int N
   __shared__ double Lr[kNB];
   const int lane = threadIdx.x;
   {
-    const bool bad = chol_diag_wave(S, N, k0, lane, Lt, Lr);
+    const bool bad = chol_diag_wave(S + (size_t)k0 * N + k0, (size_t)N, lane, Lt, Lr);
     if (bad && blockIdx.x == 0 && lane == 0) *flag = 1;
   }
   if (blockIdx.x == 0) {
