@@ -26,6 +26,7 @@
 #include "../../include/miba.h"
 #include "miba_kernels.hpp"
 #include "miba_mf.hpp"
+#include "miba_pcg.hpp"
 #include "miba_dense.hpp"
 #include "miba_sparse.hpp"
 #include "miba_plan.hpp"
@@ -168,6 +169,9 @@ struct miba_handle_s {
   bool k2_onepass = false;                        // MIBA_K2_ONEPASS=1: K2-mf with LDS-atomic camera rows in one pass
   int32_t n_giant = 0;
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
+  int n_cu = 1, dev_share = 1;                    // compute units of the device; ranks of this process that share it
+  int tail_nb = 1;                                // grid of pcg_tail: resident as a whole (it holds grid barriers)
+  unsigned* d_bar = nullptr;                      // barrier counter of pcg_tail
   bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
   int cam_model = 0;                              // MIBA_MODEL_*: camera model of the problem (miba_problem.camera_model)
   std::vector<double> principal;                  // model 1: (ox, oy) per camera that the uploaded observations carry
@@ -629,19 +633,23 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
 // pcg_iter > 0: the product of that PCG iteration.  An event pair around a launch costs two 6 us bubbles on the
 // stream, so inside the PCG the product is timed in one iteration out of h->time_every only (the first of every solve
 // among them); products outside the PCG (probes, tools) are always timed.
-int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* part_xy, int pcg_iter = 0) {
-  const bool sample = pcg_iter <= 0 || (pcg_iter - 1) % h->time_every == 0;
-  if (h->use_mf) {
-    if (h->n_tiles) {
-      Timed t(h, MIBA_K_SCHUR_MATVEC, pcg_iter, sample);
+// tile side of the matrix-free product: the raw slab rows of S x per (tile, camera)
+void mf_matvec_tiles(miba_handle h, const double* x, Ctl* ctl, int pcg_iter, bool sample) {
+  if (!h->n_tiles) return;
+  Timed t(h, MIBA_K_SCHUR_MATVEC, pcg_iter, sample);
 #define MIBA_MATVEC_ARGS                                                                                                \
   dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant, h->d_grps,  \
       h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec,        \
       (const double*)h->d_omega, x, h->d_slab9, ctl
-      if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_matvec<true>, MIBA_MATVEC_ARGS);
-      else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
+  if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_matvec<true>, MIBA_MATVEC_ARGS);
+  else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
 #undef MIBA_MATVEC_ARGS
-    }
+}
+
+int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* part_xy, int pcg_iter = 0) {
+  const bool sample = pcg_iter <= 0 || (pcg_iter - 1) % h->time_every == 0;
+  if (h->use_mf) {
+    mf_matvec_tiles(h, x, ctl, pcg_iter, sample);
     {
       Timed t(h, MIBA_K_CAM_REDUCE, pcg_iter, sample && pcg_iter > 0);
       hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
@@ -721,10 +729,100 @@ int unit_scale_masked(miba_handle h) {
   return apply_const_mask(h);
 }
 
-// ConjugateGradientsSolver::Solve on S y = rhs with x0 = 0.  Solution in d_px.
-// Per iteration: pcg_chkdir, the mat-vec (tiles + camera reduction, which also leaves the p.q partials) and
-// pcg_update; the control block is device-resident and double-buffered (see miba_kernels.hpp).
+// ConjugateGradientsSolver::Solve on S y = rhs with x0 = 0, matrix-free kernels.  Solution in d_px.
+// Per iteration two launches: the tiles' side of the product (k_mf_matvec) and pcg_tail (miba_pcg.hpp: camera-side sum, vector
+// updates, scalars, next direction); with several ranks the camera-side sum and its all-reduce stand between them.  The control
+// block is device-resident and double-buffered (see miba_kernels.hpp).
+template <int MODE>
+void launch_tail(miba_handle h, const TailArgs& A, bool reduce) {
+  if (reduce) hipLaunchKernelGGL((pcg_tail<MODE, true>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
+  else hipLaunchKernelGGL((pcg_tail<MODE, false>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
+}
+
+int pcg_solve_mf(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
+  const size_t n = 9 * (size_t)h->n_cam;
+  const int nb = h->tail_nb;
+  double* part_nb = h->d_part_pcg;
+  double* part_q = h->d_part_pcg + kPcgMaxBlocks;
+  double* part_rho[2] = {h->d_part_pcg + 2 * kPcgMaxBlocks, h->d_part_pcg + 3 * kPcgMaxBlocks};
+  classify_pcg_events(h, 1 << 30);   // pairs a solve that ended in an error has left behind are not kept waiting
+  const bool multi = multi_rank(h);
+  TailArgs A{};
+  A.n_cam = h->n_cam;
+  A.cam_row_off = h->d_cam_row_off; A.slab = h->d_slab9; A.ct = h->d_ct; A.cm = h->d_cm; A.sc = h->d_sc; A.d2 = h->d_Dc2;
+  A.diag_w = h->cfg.rank == 0 ? 1.0 : 0.0;
+  A.p = h->d_pp; A.q = h->d_pq; A.b = h->d_rhs; A.Minv = h->d_Minv; A.x = h->d_px; A.r = h->d_pr; A.z = h->d_pz;
+  A.ctl = h->d_ctl;
+  // one rank: the tail's own p.q partials; several ranks: the camera reduction's, behind q so that one all-reduce takes both
+  A.part_pq = multi ? h->d_pq + n : h->d_part_pcg + 4 * kPcgMaxBlocks;
+  A.n_pq = multi ? h->red_nb : nb;
+  A.part_q = part_q; A.part_rho0 = part_rho[0]; A.part_rho1 = part_rho[1];
+  A.q_tol = q_tol; A.min_it = min_it; A.max_it = max_it;
+  A.bar = h->d_bar;
+  HIPCHK(h, hipMemsetAsync(h->d_bar, 0, sizeof(unsigned), h->st));
+  hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
+                     part_nb, part_rho[1]);
+  hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_nb, nb, h->d_ctl);
+  hipLaunchKernelGGL(pcg_chkdir, dim3(nb), dim3(256), 0, h->st, 1, n, h->d_pz, h->d_pp, h->d_ctl, part_rho[0], part_rho[1], nb, A.part_pq,
+                     A.n_pq, part_q, q_tol, min_it, max_it);
+  HIPCHK(h, hipGetLastError());
+  if (check_every < 1) check_every = 1;
+  // camera-side sum and all-reduce as launches of their own (several ranks)
+  auto reduce_step = [&](const double* v, bool with_pq, int j, bool sample) -> int {
+    {
+      Timed t(h, MIBA_K_CAM_REDUCE, j, sample);
+      hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
+                         h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, v, A.diag_w, h->d_pq, with_pq ? A.part_pq : (double*)nullptr,
+                         h->d_ctl + ((j - 1) & 1));
+    }
+    HIPCHK(h, hipGetLastError());
+    return allreduce(h, h->d_pq, n + (with_pq ? (size_t)h->red_nb : 0), ncclSum);
+  };
+  for (int j = 1;; ++j) {
+    Ctl* cur = h->d_ctl + ((j - 1) & 1);   // C_{j-1}: state after the j-1 iterations tested so far
+    const int it = j - 1;
+    // Host poll: the control block is copied out and marked by an event, iteration j is enqueued behind it, and only
+    // then does the host wait for the copy: the device works on iteration j while the host looks at C_{j-1}, instead
+    // of idling for a host round trip (34 us per poll at Final-13682).  If C_{j-1} says done, iteration j's kernels
+    // return at once, like every launch enqueued past convergence.
+    const bool poll = it >= 1 && (it % check_every == 0 || it >= max_it);
+    if (poll) {
+      HIPCHK(h, hipMemcpyAsync(h->h_ctl, cur, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
+      HIPCHK(h, hipEventRecord(h->ev_poll, h->st));
+    }
+    const bool sample = (j - 1) % h->time_every == 0;
+    const bool reset = (j % 10 == 0);  // residual_reset_period
+    A.j = j;
+    int rc = MIBA_OK;
+    mf_matvec_tiles(h, h->d_pp, cur, j, sample);
+    if (multi && (rc = reduce_step(h->d_pp, true, j, sample))) return rc;
+    if (!reset) {
+      Timed t(h, multi ? -1 : MIBA_K_CAM_REDUCE, j, sample && !multi);
+      launch_tail<0>(h, A, !multi);
+    } else {
+      launch_tail<1>(h, A, !multi);
+      HIPCHK(h, hipGetLastError());
+      mf_matvec_tiles(h, h->d_px, cur, j, sample);   // q = S p is dead once x is updated: reuse it for S x
+      if (multi && (rc = reduce_step(h->d_px, false, j, false))) return rc;
+      launch_tail<2>(h, A, !multi);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (poll) {
+      HIPCHK(h, hipEventSynchronize(h->ev_poll));
+      if (h->h_ctl->done) break;
+      if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
+    }
+  }
+  if (h->h_ctl->fail & 16) return fail(h, MIBA_ERR_HIP, "the PCG tail kernel's grid barrier timed out (its grid was not resident as a whole)");
+  *n_it = h->h_ctl->n_it;
+  *status = h->h_ctl->status;
+  classify_pcg_events(h, *n_it);
+  return MIBA_OK;
+}
+
+// the same on the stored Jacobian (MIBA_MF=0): pcg_chkdir, product, pcg_dot, pcg_update per iteration
 int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
+  if (h->use_mf) return pcg_solve_mf(h, q_tol, min_it, max_it, check_every, n_it, status);
   const size_t n = 9 * (size_t)h->n_cam;
   const int nb = h->pcg_nb;
   double* part_nb = h->d_part_pcg;
@@ -1394,6 +1492,7 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_ctl, sizeof(Ctl));
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming);
   if (e == hipSuccess) e = static_scratch_for(dev, &h->static_scratch);   // device `dev` is current here
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   if (const char* te = getenv("MIBA_TIME_EVERY")) { const int v = atoi(te); if (v >= 1) h->time_every = v; }
   if (e != hipSuccess) {
     int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
@@ -1490,7 +1589,12 @@ int miba_create_multi(const int32_t* device_ids, int32_t n_devices, int32_t log_
   int rc = MIBA_OK;
   for (int r = 0; r < n_devices && rc == MIBA_OK; ++r) {
     rc = create_rank(dev[r], r, n_devices, log_level, &G->sub[r]);
-    if (rc == MIBA_OK) G->sub[r]->grp = G;
+    if (rc == MIBA_OK) {
+      G->sub[r]->grp = G;
+      int share = 0;
+      for (int q = 0; q < n_devices; ++q) share += dev[q] == dev[r];
+      G->sub[r]->dev_share = share;
+    }
   }
   if (rc == MIBA_OK && n_devices > 1) {
     if (G->mode == kCommRccl) {
@@ -1690,6 +1794,9 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   h->pcg_nb = std::min(nblk(p->n_cam, kPcgCams), kPcgMaxBlocks);
   h->red_cpb = 4 * nblk(p->n_cam, 4 * kPcgMaxBlocks);
   h->red_nb = nblk(p->n_cam, h->red_cpb);
+  // the tail kernel of a PCG iteration holds grid barriers: its grid must be resident as a whole.  One 1024-thread workgroup per
+  // compute unit at most; ranks of this process that share the device share its compute units.
+  h->tail_nb = std::max(1, std::min(nblk(p->n_cam, kTailCams), h->n_cu / std::max(1, h->dev_share)));
   h->t0 = P.shard_tile[h->cfg.rank];
   h->t1 = P.shard_tile[h->cfg.rank + 1];
   h->n_tiles = h->t1 - h->t0;
@@ -1839,6 +1946,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   ALLOC(h->d_part_pcg, 5 * (size_t)kPcgMaxBlocks);
   ALLOC(h->d_sum, S_COUNT); ALLOC(h->d_max, S_COUNT);
   ALLOC(h->d_ctl, 2);
+  ALLOC(h->d_bar, 64);
   UP(h->d_tiles, tiles.data(), nt);
   UP(h->d_grps, grps.data(), grps.size());
   UP(h->d_idx, P.idx.data() + h->slot_base, ns);
