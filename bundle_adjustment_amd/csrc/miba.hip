@@ -170,7 +170,7 @@ struct miba_handle_s {
   int32_t n_giant = 0;
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   int n_cu = 1, dev_share = 1;                    // compute units of the device; ranks of this process that share it
-  int tail_nb = 1;                                // grid of pcg_tail: resident as a whole (it holds grid barriers)
+  int tail_nb = 1, tail_cpw = 7;                  // grid of pcg_tail: resident as a whole (it holds grid barriers); cameras per wave
   unsigned* d_bar = nullptr;                      // barrier counter of pcg_tail
   bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
   int cam_model = 0;                              // MIBA_MODEL_*: camera model of the problem (miba_problem.camera_model)
@@ -749,6 +749,7 @@ int pcg_solve_mf(miba_handle h, double q_tol, int min_it, int max_it, int check_
   const bool multi = multi_rank(h);
   TailArgs A{};
   A.n_cam = h->n_cam;
+  A.cpw = h->tail_cpw;
   A.cam_row_off = h->d_cam_row_off; A.slab = h->d_slab9; A.ct = h->d_ct; A.cm = h->d_cm; A.sc = h->d_sc; A.d2 = h->d_Dc2;
   A.diag_w = h->cfg.rank == 0 ? 1.0 : 0.0;
   A.p = h->d_pp; A.q = h->d_pq; A.b = h->d_rhs; A.Minv = h->d_Minv; A.x = h->d_px; A.r = h->d_pr; A.z = h->d_pz;
@@ -1438,7 +1439,7 @@ void miba_default_options(miba_options* o) {
   o->max_num_consecutive_invalid_steps = 5;
   o->update_state_every_iteration = 0;
   o->minimizer_progress_to_stdout = 0;
-  o->pcg_check_every = 1;
+  o->pcg_check_every = 4;
   o->initial_trust_region_radius = 1e4;
   o->max_trust_region_radius = 1e16;
   o->min_trust_region_radius = 1e-32;
@@ -1796,7 +1797,8 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   h->red_nb = nblk(p->n_cam, h->red_cpb);
   // the tail kernel of a PCG iteration holds grid barriers: its grid must be resident as a whole.  One 1024-thread workgroup per
   // compute unit at most; ranks of this process that share the device share its compute units.
-  h->tail_nb = std::max(1, std::min(nblk(p->n_cam, kTailCams), h->n_cu / std::max(1, h->dev_share)));
+  h->tail_nb = std::max(1, std::min(nblk(p->n_cam, kTailWaves), h->n_cu / std::max(1, h->dev_share)));
+  h->tail_cpw = std::max(1, std::min(7, nblk(p->n_cam, h->tail_nb * kTailWaves)));
   h->t0 = P.shard_tile[h->cfg.rank];
   h->t1 = P.shard_tile[h->cfg.rank + 1];
   h->n_tiles = h->t1 - h->t0;

@@ -906,7 +906,7 @@ __global__ void k_pack_scalars(double* __restrict__ acc, double* __restrict__ su
 // so that M is the block diagonal of S itself (the LM diagonal is still taken from F'F).
 __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const double* __restrict__ acc2, const uint8_t* __restrict__ active,
                              const double* __restrict__ sc, double inv_radius, double dmin, double dmax,
-                             double* __restrict__ Minv /*[n][81]*/, double* __restrict__ Dc2 /*[n][9]*/,
+                             double* __restrict__ Minv /*[n][81], column-major blocks*/, double* __restrict__ Dc2 /*[n][9]*/,
                              double* __restrict__ rhs /*[n][9]*/, double* __restrict__ partial /*[nblk][2]*/,
                              Ctl* __restrict__ ctl) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -966,7 +966,7 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const do
           for (int k = i + 1; k < 9; ++k) s -= L[k * 9 + i] * col[k];
           col[i] = s / L[i * 9 + i];
         }
-        for (int i = 0; i < 9; ++i) Mi[i * 9 + j] = col[i];
+        for (int i = 0; i < 9; ++i) Mi[j * 9 + i] = col[i];   // column-major: entry (i, j) at 9 j + i (the PCG kernels read it lane = row)
       }
     }
   }
@@ -1102,10 +1102,10 @@ __global__ __launch_bounds__(256) void pcg_start(int n_cam, const double* __rest
     if (act) { v = b[i]; x[i] = 0.0; r[i] = v; s_r[tid] = v; a_nb += v * v; }
     __syncthreads();
     if (act) {
-      const double* m = Minv + 9 * i;   // row k of the camera's 9x9 block
+      const double* m = Minv + 81 * (size_t)c + k;   // row k of the camera's 9x9 block (stored column-major)
       double zz = 0.0;
 #pragma unroll
-      for (int j = 0; j < 9; ++j) zz += m[j] * s_r[9 * cl + j];
+      for (int j = 0; j < 9; ++j) zz += m[9 * j] * s_r[9 * cl + j];
       z[i] = zz;
       a_rho += v * zz;
     }
@@ -1248,10 +1248,10 @@ __global__ __launch_bounds__(256) void pcg_update(int n_cam, const double* __res
     if (MODE != 1) {
       __syncthreads();
       if (act) {
-        const double* m = Minv + 9 * i;
+        const double* m = Minv + 81 * (size_t)c + k;
         double zz = 0.0;
 #pragma unroll
-        for (int jj = 0; jj < 9; ++jj) zz += m[jj] * s_r[9 * cl + jj];
+        for (int jj = 0; jj < 9; ++jj) zz += m[9 * jj] * s_r[9 * cl + jj];
         z[i] = zz;
         a_rho += rv * zz;
       }

@@ -10,6 +10,10 @@
 //   C  end-of-iteration test (Q tolerance, limits), beta, p = z + beta p, control block of the next iteration
 // on a grid that is resident as a whole (at most one 1024-thread workgroup per CU), with the barrier on one device-scope
 // counter.  Every workgroup derives the scalars from the same partial arrays in the same order, so all take the same branch.
+// The only data that cross workgroups inside the kernel are those partial sums; they are written and read with device-scope
+// atomic stores and loads, so the barrier needs no release / acquire fence: on gfx950 each such fence writes back or invalidates
+// the L2 of the XCD, and the fences of a grid serialise (measured, tools/micro/grid_barrier_bench.hip: 34 us per barrier for 256
+// workgroups with them, 3.6 us without; 2.0 us for 128 workgroups).
 // A barrier that is not reached within two seconds (the grid was not resident after all) ends the solve with a failure status
 // instead of hanging.  With several ranks the camera-side sum stays a kernel of its own (the all-reduce sits behind it) and
 // the tail starts at B.
@@ -22,6 +26,7 @@ namespace miba {
 constexpr int kTailThreads = 1024;
 constexpr int kTailWaves = kTailThreads / 64;
 constexpr int kTailCams = 7 * kTailWaves;   // cameras per workgroup round: 7 per wave, nine lanes each
+constexpr int kTailBatch = 12;              // slab loads in flight per lane (84 rows per wave and batch)
 
 // sum over the 1024-thread workgroup, the same value in every thread; s16: 16 doubles of LDS
 __device__ __forceinline__ double tail_block_sum(double v, double* s16) {
@@ -34,56 +39,64 @@ __device__ __forceinline__ double tail_block_sum(double v, double* s16) {
   for (int i = 0; i < kTailWaves; ++i) t += s16[i];
   return t;
 }
-__device__ __forceinline__ double tail_sum_partials(const double* __restrict__ part, int n, double* s16) {
+// partial sums cross workgroups: device-scope stores and loads (see the head of the file)
+__device__ __forceinline__ void tail_put(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double tail_get(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double tail_sum_partials(const double* part, int n, double* s16) {
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += kTailThreads) v += part[i];
+  for (int i = threadIdx.x; i < n; i += kTailThreads) v += tail_get(part + i);
   return tail_block_sum(v, s16);
 }
 
 // All workgroups of the grid meet.  count only grows (the host clears it before a solve): arrival number a belongs to barrier
-// a / n_blocks.  Release before arriving, acquire after leaving (device scope: the L2 of another XCD may hold the old lines).
-// Returns false when the others did not arrive in time.
+// a / n_blocks.  Thread 0 is also the thread that has stored the workgroup's partial sums: it waits for those stores to be
+// acknowledged (workgroup-scope release = s_waitcnt, no cache maintenance) before it arrives.  Returns false when the others
+// did not arrive in time.
 __device__ __forceinline__ bool tail_grid_barrier(unsigned* count, unsigned n_blocks, int* s_ok) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = (old / n_blocks + 1u) * n_blocks;
     const long long t0 = wall_clock64();
     int ok = 1;
     while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t0 > 200000000ll) { ok = 0; break; }   // 2 s of the 100 MHz counter
     }
     *s_ok = ok;
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return *s_ok != 0;
 }
 
-// camera-side transforms of the summed raw slab row v[0..8] of camera c, entry k (the text of k_cam_reduce_mf)
-// (own = v[k], the lane's own sum: no register array is indexed with k)
-__device__ __forceinline__ double tail_cam_entry(int k, double v0, double v1, double v2, double v3, double v4, double v5, double own,
-                                                 const double* __restrict__ T, const double* __restrict__ M) {
-  const bool small = M[9] == 1.0;
-  double r;
-  if (M[9] == 2.0) {
+// Camera-side transforms of the summed raw slab row (v0..v5 = its rotation and translation parts, own = entry k) as seven
+// coefficients per lane, r = c0 v0 + ... + c5 v5 + c6 own, loaded BEFORE the rows are summed so that nothing waits on memory
+// afterwards.  The transforms of k_cam_reduce_mf: BAL camera: (M' c)_k | (N a)_i (a itself at small angles) | i_f | f i_k1 |
+// f i_k2.  The reference's functor (flag 2): rotation part M~'(t x a - c) = (m x t).a - m.c with m = column k of M~ and
+// t = -R~' t~, translation part -a, intrinsics constant.
+__device__ __forceinline__ void tail_cam_coef(int k, const double* __restrict__ T, const double* __restrict__ M, double* c /*[7]*/) {
+#pragma unroll
+  for (int m = 0; m < 7; ++m) c[m] = 0.0;
+  const double flag = M[9];
+  if (flag == 2.0) {
     if (k < 3) {
       const double t0 = -(T[0] * T[9] + T[3] * T[10] + T[6] * T[11]);
       const double t1 = -(T[1] * T[9] + T[4] * T[10] + T[7] * T[11]);
       const double t2 = -(T[2] * T[9] + T[5] * T[10] + T[8] * T[11]);
-      const double u0 = t1 * v5 - t2 * v4 - v0, u1 = t2 * v3 - t0 * v5 - v1, u2 = t0 * v4 - t1 * v3 - v2;
-      r = M[k] * u0 + M[3 + k] * u1 + M[6 + k] * u2;
-    } else if (k < 6) r = -own;
-    else r = 0.0;
-  } else if (k < 3) r = M[k] * v0 + M[3 + k] * v1 + M[6 + k] * v2;
+      const double m0 = M[k], m1 = M[3 + k], m2 = M[6 + k];
+      c[0] = -m0; c[1] = -m1; c[2] = -m2;
+      c[3] = m1 * t2 - m2 * t1; c[4] = m2 * t0 - m0 * t2; c[5] = m0 * t1 - m1 * t0;
+    } else if (k < 6) c[6] = -1.0;
+  } else if (k < 3) { c[0] = M[k]; c[1] = M[3 + k]; c[2] = M[6 + k]; }
   else if (k < 6) {
     const int i = k - 3;
-    r = small ? own : (T[3 * i] * v3 + T[3 * i + 1] * v4 + T[3 * i + 2] * v5);
-  } else if (k == 6) r = own;
-  else r = T[12] * own;
-  return r;
+    if (flag == 1.0) c[6] = 1.0;
+    else { c[3] = T[3 * i]; c[4] = T[3 * i + 1]; c[5] = T[3 * i + 2]; }
+  } else if (k == 6) c[6] = 1.0;
+  else c[6] = T[12];
 }
 
 // a barrier timed out: the solve ends as a failure in both control blocks (bit 16 of fail tells the host why)
@@ -94,6 +107,7 @@ __device__ __forceinline__ void tail_timed_out(Ctl* ctl) {
 struct TailArgs {
   int j;            // PCG iteration (1-based) this launch completes
   int n_cam;
+  int cpw;          // cameras per wave and round, 1..7 (nine lanes each)
   // camera-side sum (phase A)
   const int32_t* cam_row_off; const double* slab; const double* ct; const double* cm; const double* sc; const double* d2;
   double diag_w;
@@ -108,62 +122,138 @@ struct TailArgs {
   unsigned* bar;       // barrier counter
 };
 
+// two partial-sum arrays in one pass (one trip to memory instead of two)
+__device__ __forceinline__ void tail_sum_partials2(const double* pa, int na, const double* pb, int nb, double* s32, double& sa, double& sb) {
+  double va = 0.0, vb = 0.0;
+  for (int i = threadIdx.x; i < na; i += kTailThreads) va += tail_get(pa + i);
+  for (int i = threadIdx.x; i < nb; i += kTailThreads) vb += tail_get(pb + i);
+  va = wave_sum(va);
+  vb = wave_sum(vb);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s32[threadIdx.x >> 6] = va; s32[kTailWaves + (threadIdx.x >> 6)] = vb; }
+  __syncthreads();
+  sa = 0.0; sb = 0.0;
+#pragma unroll
+  for (int i = 0; i < kTailWaves; ++i) { sa += s32[i]; sb += s32[kTailWaves + i]; }
+}
+
 // MODE 0: the whole tail of iteration j.
 // MODE 1: residual-reset iteration, first half: A, alpha, x += alpha p (r is rebuilt from S x by MODE 2 after another product).
 // MODE 2: second half: A on q = S x (no p.q), r = b - q, Q, z, r.z, then C.
 // REDUCE: phase A is part of this launch (one rank); otherwise q and the p.q partials are there already.
+//
+// Lane (sub, k) of a wave owns entry k of camera cam0 + sub (cpw cameras per wave, nine lanes each).  When one round covers all
+// cameras (single: up to 7 x 16 x 256 = 28,672 of them) the entries of x, p, r, b and the row of M^-1 are loaded before the first
+// barrier and stay in registers through all three phases: after a barrier only the partial sums are fetched.
+//
+// Phase A reads the slab rows of the wave's cameras as ONE contiguous range (the rows of consecutive cameras follow each other):
+// lane (g, k) takes rows g, g + 7, g + 14, ... so that a load instruction covers 504 contiguous bytes whatever the row counts
+// of the cameras are; a lane's rows run through the cameras in order, and it hands its sum to LDS each time it crosses into
+// the next camera; the camera's lanes then add the seven partial sums in a fixed order.
 template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
-  __shared__ double s16[kTailWaves];
+  __shared__ double s32[2 * kTailWaves];
   __shared__ int s_ok;
+  __shared__ int s_bnd[kTailWaves * 8];
+  __shared__ double s_wp[REDUCE ? kTailWaves * 7 * 64 : 1];
   const int j = a.j;
   Ctl c = a.ctl[(j - 1) & 1];   // C_{j-1}
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   if (c.done) {
-    if (writer) a.ctl[j & 1] = c;   // the final state in both buffers
+    if (writer && MODE != 1) a.ctl[j & 1] = c;   // the final state in both buffers
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int sub = lane / 9, k = lane - 9 * sub;
   const int nb = gridDim.x;
-  const int first = (blockIdx.x * kTailWaves + wv) * 7 + sub, stride = nb * kTailCams;
-  const bool lane_on = lane < 63;
+  const int wave_first = (blockIdx.x * kTailWaves + wv) * a.cpw, stride = nb * kTailWaves * a.cpw;
+  const bool single = stride >= a.n_cam;   // one round: values are carried in registers
+  const bool lane_on = sub < a.cpw;
   double* part_rho_cur = (j & 1) ? a.part_rho1 : a.part_rho0;
   double* part_rho_next = (j & 1) ? a.part_rho0 : a.part_rho1;
+  // carried through the phases when single (entry k of the lane's camera)
+  double c_x = 0.0, c_p = 0.0, c_r = 0.0, c_b = 0.0, c_q = 0.0, c_z = 0.0, c_M[9];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) c_M[m] = 0.0;
 
   // ---- A: q = S v over the cameras of this wave (v = p, or x in MODE 2) ----
   if (REDUCE) {
     const double* v_in = (MODE == 2) ? a.x : a.p;
     double xy = 0.0;
-    for (int cc = first; cc - sub < a.n_cam; cc += stride) {   // (the whole wave leaves together: the shuffles need every lane)
-      const bool on = lane_on && cc < a.n_cam;
-      const int cam = on ? cc : 0;
-      const int r0 = on ? a.cam_row_off[cam] : 0, r1 = on ? a.cam_row_off[cam + 1] : 0;
+    double* wp = s_wp + (size_t)wv * 7 * 64;
+    int* bnd = s_bnd + wv * 8;
+    for (int cam0 = wave_first; cam0 < a.n_cam; cam0 += stride) {
+      const int ncw = min(a.cpw, a.n_cam - cam0);
+      const bool on = sub < ncw;
+      const int cam = on ? cam0 + sub : cam0;
       const size_t i = 9 * (size_t)cam + k;
+      const int bl = a.cam_row_off[cam0 + min(lane, ncw)];
       const double xv = on ? v_in[i] : 0.0;
       const double scv = on ? a.sc[i] : 0.0, d2v = on ? a.d2[i] : 0.0;
+      double cf[7];
+      tail_cam_coef(k, a.ct + (size_t)kCamTabStride * cam, a.cm + 10 * (size_t)cam, cf);
+      if (single && on) {
+        if (MODE != 2) { c_p = xv; c_x = a.x[i]; } else c_x = xv;
+        if (MODE != 1) {
+          c_b = a.b[i];
+          if (MODE == 0) c_r = a.r[i];
+#pragma unroll
+          for (int m = 0; m < 9; ++m) c_M[m] = a.Minv[81 * (size_t)cam + 9 * m + k];
+        }
+      }
+      if (lane < 8) bnd[lane] = bl;
+#pragma unroll
+      for (int q7 = 0; q7 < 7; ++q7) wp[q7 * 64 + lane] = 0.0;
+      __builtin_amdgcn_wave_barrier();
+      const int R0 = __shfl(bl, 0, 64), R1 = __shfl(bl, ncw, 64);
+      int cj = 0, b_next = bnd[1];
       double acc = 0.0;
       const double* sp = a.slab + k;
-      int r = r0;
-      for (; r + 4 <= r1; r += 4) {
-        const double s0 = sp[9 * (size_t)r], s1 = sp[9 * (size_t)(r + 1)], s2 = sp[9 * (size_t)(r + 2)], s3 = sp[9 * (size_t)(r + 3)];
-        acc += s0; acc += s1; acc += s2; acc += s3;
+      const bool row_lane = lane < 63;
+      for (int t0 = 0; R0 + 7 * t0 < R1; t0 += kTailBatch) {
+        double t[kTailBatch];
+#pragma unroll
+        for (int m = 0; m < kTailBatch; ++m) {
+          const int row = R0 + sub + 7 * (t0 + m);
+          t[m] = (row_lane && row < R1) ? sp[9 * (size_t)row] : 0.0;
+        }
+#pragma unroll
+        for (int m = 0; m < kTailBatch; ++m) {
+          const int row = R0 + sub + 7 * (t0 + m);
+          if (row_lane && row < R1) {
+            while (row >= b_next) {   // into the next camera (row < R1 = the last boundary: cj stays below ncw)
+              wp[cj * 64 + lane] = acc;
+              acc = 0.0;
+              ++cj;
+              b_next = bnd[cj + 1];
+            }
+            acc += t[m];
+          }
+        }
       }
-      for (; r < r1; ++r) acc += sp[9 * (size_t)r];
-      const int l0 = 9 * sub;   // the first six sums of the camera (rotation and translation parts) to all of its lanes
-      const double v0 = __shfl(acc, l0, 64), v1 = __shfl(acc, l0 + 1, 64), v2 = __shfl(acc, l0 + 2, 64);
-      const double v3 = __shfl(acc, l0 + 3, 64), v4 = __shfl(acc, l0 + 4, 64), v5 = __shfl(acc, l0 + 5, 64);
+      if (row_lane) wp[cj * 64 + lane] = acc;
+      __builtin_amdgcn_wave_barrier();
+      double tot = 0.0;
       if (on) {
-        double rr = tail_cam_entry(k, v0, v1, v2, v3, v4, v5, acc, a.ct + (size_t)kCamTabStride * cam, a.cm + 10 * (size_t)cam);
+#pragma unroll
+        for (int g = 0; g < 7; ++g) tot += wp[sub * 64 + 9 * g + k];
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int l0 = 9 * sub;   // the first six sums of the camera (rotation and translation parts) to all of its lanes
+      const double v0 = __shfl(tot, l0, 64), v1 = __shfl(tot, l0 + 1, 64), v2 = __shfl(tot, l0 + 2, 64);
+      const double v3 = __shfl(tot, l0 + 3, 64), v4 = __shfl(tot, l0 + 4, 64), v5 = __shfl(tot, l0 + 5, 64);
+      if (on) {
+        double rr = cf[0] * v0 + cf[1] * v1 + cf[2] * v2 + cf[3] * v3 + cf[4] * v4 + cf[5] * v5 + cf[6] * tot;
         rr *= scv;
         rr += a.diag_w * d2v * xv;
-        a.q[i] = rr;
+        if (single) c_q = rr;
+        else a.q[i] = rr;
         xy += xv * rr;
       }
     }
     if (MODE != 2) {
-      const double s = tail_block_sum(xy, s16);
-      if (tid == 0) a.part_pq[blockIdx.x] = s;
+      const double s = tail_block_sum(xy, s32);
+      if (tid == 0) tail_put(a.part_pq + blockIdx.x, s);
       if (!tail_grid_barrier(a.bar, nb, &s_ok)) {
         if (writer) tail_timed_out(a.ctl);
         return;
@@ -173,42 +263,57 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
 
   // ---- B: alpha and the vector updates ----
   const int n_pq = REDUCE ? nb : a.n_pq;
-  const double rho = tail_sum_partials(part_rho_cur, nb, s16);
-  const double pq = tail_sum_partials(a.part_pq, n_pq, s16);
+  double rho, pq;
+  tail_sum_partials2(part_rho_cur, nb, a.part_pq, n_pq, s32, rho, pq);
   const bool pq_bad = pq <= 0.0 || isinf(pq) || isnan(pq);
   const double alpha = rho / pq;
   const bool alpha_bad = !pq_bad && isinf(alpha);
+  const bool carried = REDUCE && single;
   if (!pq_bad && !alpha_bad) {
     double a_q = 0.0, a_rho = 0.0;
-    for (int cc = first; cc - sub < a.n_cam; cc += stride) {
-      const bool on = lane_on && cc < a.n_cam;
-      const size_t i = 9 * (size_t)(on ? cc : 0) + k;
-      double rv = 0.0, xv = 0.0, bv = 0.0;
+    for (int cam0 = wave_first; cam0 < a.n_cam; cam0 += stride) {
+      const bool on = lane_on && cam0 + sub < a.n_cam;
+      const int cam = on ? cam0 + sub : cam0;
+      const size_t i = 9 * (size_t)cam + k;
+      double rv = 0.0, xv = 0.0;
       if (on) {
-        if (MODE == 2) xv = a.x[i];
-        else { xv = a.x[i] + alpha * a.p[i]; a.x[i] = xv; }
+        if (MODE == 2) xv = carried ? c_x : a.x[i];
+        else { xv = (carried ? c_x : a.x[i]) + alpha * (carried ? c_p : a.p[i]); a.x[i] = xv; }
         if (MODE != 1) {
-          bv = a.b[i];
-          rv = (MODE == 0) ? a.r[i] - alpha * a.q[i] : bv - a.q[i];
+          const double bv = carried ? c_b : a.b[i];
+          const double qv = carried ? c_q : a.q[i];
+          rv = (MODE == 0) ? (carried ? c_r : a.r[i]) - alpha * qv : bv - qv;
           a.r[i] = rv;
           a_q += xv * (bv + rv);
         }
       }
       if (MODE != 1) {
-        const double* mrow = a.Minv + 9 * i;
         double zz = 0.0;
 #pragma unroll
-        for (int m = 0; m < 9; ++m) zz += (on ? mrow[m] : 0.0) * __shfl(rv, 9 * sub + m, 64);
+        for (int m = 0; m < 9; ++m) {
+          const double mv = carried ? c_M[m] : (on ? a.Minv[81 * (size_t)cam + 9 * m + k] : 0.0);
+          zz += mv * __shfl(rv, 9 * sub + m, 64);
+        }
         if (on) {
           a.z[i] = zz;
+          c_z = zz;
           a_rho += rv * zz;
         }
       }
     }
     if (MODE != 1) {
-      const double sq = tail_block_sum(a_q, s16);
-      const double sr = tail_block_sum(a_rho, s16);
-      if (tid == 0) { a.part_q[blockIdx.x] = sq; part_rho_next[blockIdx.x] = sr; }
+      // both block sums in one pass
+      const double wq = wave_sum(a_q), wr = wave_sum(a_rho);
+      __syncthreads();
+      if (lane == 0) { s32[wv] = wq; s32[kTailWaves + wv] = wr; }
+      __syncthreads();
+      if (tid == 0) {
+        double sq = 0.0, sr = 0.0;
+#pragma unroll
+        for (int m = 0; m < kTailWaves; ++m) { sq += s32[m]; sr += s32[kTailWaves + m]; }
+        tail_put(a.part_q + blockIdx.x, sq);
+        tail_put(part_rho_next + blockIdx.x, sr);
+      }
     }
   }
   if (MODE == 1) return;
@@ -218,6 +323,8 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   }
 
   // ---- C: end of iteration j, direction of iteration j + 1 (pcg_chkdir(j + 1)) ----
+  double qs = 0.0, rho_n = 0.0;
+  if (!pq_bad && !alpha_bad) tail_sum_partials2(a.part_q, nb, part_rho_next, nb, s32, qs, rho_n);
   c.n_it = j;
   c.pq = pq;
   if (pq_bad) { c.done = 1; c.status = 1; }
@@ -225,7 +332,6 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
     c.alpha = alpha;
     if (alpha_bad) { c.done = 1; c.status = 2; }
     else {
-      const double qs = tail_sum_partials(a.part_q, nb, s16);
       const double Q1 = -qs;
       const double zeta = j * (Q1 - c.Q0) / Q1;
       c.Q1 = Q1;
@@ -241,7 +347,6 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
     if (writer) a.ctl[j & 1] = c;
     return;
   }
-  const double rho_n = tail_sum_partials(part_rho_next, nb, s16);
   bool bad = pcg_bad(rho_n);
   double beta = 0.0;
   if (!bad) {
@@ -254,10 +359,12 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   if (bad) { c.done = 1; c.status = 2; c.n_it = j + 1; }
   if (writer) a.ctl[j & 1] = c;
   if (bad) return;
-  for (int cc = first; cc - sub < a.n_cam; cc += stride) {
-    if (lane_on && cc < a.n_cam) {
-      const size_t i = 9 * (size_t)cc + k;
-      a.p[i] = a.z[i] + beta * a.p[i];
+  for (int cam0 = wave_first; cam0 < a.n_cam; cam0 += stride) {
+    if (lane_on && cam0 + sub < a.n_cam) {
+      const size_t i = 9 * (size_t)(cam0 + sub) + k;
+      // MODE 2 has carried x as the product's input, not p
+      const double pv = (carried && MODE == 0) ? c_p : a.p[i];
+      a.p[i] = (carried ? c_z : a.z[i]) + beta * pv;
     }
   }
 }

@@ -150,8 +150,18 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   }
   lap("filter");
   // Tile size: 16 chunks once that still leaves a thousand tiles (fewer tile prologues and less padding: 3.5 % on the
-  // LM iteration at Final-13682 against 8 chunks, measured with tools/ab_tile_chunks.sh), else the default.
-  if (max_chunks == 0) max_chunks = (P.n_valid >= ((int64_t)4 << 20)) ? 16 : kMaxChunksPerTile;
+  // LM iteration at Final-13682 against 8 chunks, measured with tools/ab_tile_chunks.sh).  Below that the largest power of
+  // two that leaves about 600 tiles: a small problem is latency-bound, a workgroup walks its chunks one after the other, and
+  // 256 compute units want a tile each (trafalgar-257, 226 k observations: 37.8 us per PCG iteration with 8 chunks, 32.5-34 us
+  // with 1-4; dubrovnik-356, 1.26 M: 49.6 us with 8, 55.9 with 2).
+  if (max_chunks == 0) {
+    if (P.n_valid >= ((int64_t)4 << 20)) max_chunks = 16;
+    else {
+      const int64_t want = P.n_valid / (kChunk * 600);
+      max_chunks = 1;
+      while (max_chunks < kMaxChunksPerTile && 2 * max_chunks <= want) max_chunks *= 2;
+    }
+  }
   P.n_active_cam = 0;
   for (int c = 0; c < n_cam; ++c) P.n_active_cam += P.cam_active[c];
   // --- order active points

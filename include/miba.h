@@ -120,8 +120,9 @@ typedef struct {
   int32_t max_num_consecutive_invalid_steps;/* 5 */
   int32_t update_state_every_iteration;     /* src/BundleAdjustment.cpp:104 */
   int32_t minimizer_progress_to_stdout;     /* app/main.cpp:26 */
-  int32_t pcg_check_every;                  /* host looks at the device PCG status every N its (>=1); the next iteration is
-                                               enqueued before the host waits, so a poll does not stall the stream */
+  int32_t pcg_check_every;                  /* host looks at the device PCG status every N its (>=1, default 4); the next iteration
+                                               is enqueued before the host waits, so a look does not stall the stream; the
+                                               device decides termination itself, launches enqueued past it return at once */
   int32_t preconditioner_type;              /* MIBA_PRECOND_*: ceres::Solver::Options::preconditioner_type for
                                                ITERATIVE_SCHUR; the reference leaves Ceres' default, JACOBI */
   double initial_trust_region_radius;       /* 1e4 */

@@ -92,9 +92,13 @@ def test_group_agrees_with_single_rank(single, world):
 
 
 def test_group_agrees_with_single_rank_empty_shards(single):
-    """Eight ranks for a problem of seven default-size tiles: at least one rank owns nothing and still has to take
+    """Eight ranks for a problem of seven eight-chunk tiles: at least one rank owns nothing and still has to take
     part in every reduction with zeros."""
-    pl = miba.plan_shards(40, 3000, *problem("medium")[2:5], 8)
+    os.environ["MIBA_TILE_CHUNKS"] = "8"
+    try:
+        pl = miba.plan_shards(40, 3000, *problem("medium")[2:5], 8)
+    finally:
+        os.environ.pop("MIBA_TILE_CHUNKS", None)
     assert min(pl["tiles_per_rank"]) == 0
     check(run(8, "medium", {"MIBA_TILE_CHUNKS": "8"}), single)
 

@@ -10,7 +10,7 @@ rows = list(c.execute("select name,start,end from kernels order by start"))
 short = lambda n: re.sub(r"\(.*$", "", n).replace("void ", "").replace("miba::", "")
 names = [short(r[0]) for r in rows]
 first = min(i for i, n in enumerate(names) if n.startswith("k_mf_matvec"))
-last = max(i for i, n in enumerate(names) if n.startswith("pcg_update"))
+last = max(i for i, n in enumerate(names) if n.startswith("pcg_tail") or n.startswith("pcg_update"))
 gaps = collections.defaultdict(lambda: [0, 0.0, 0.0])
 busy = 0.0
 for i in range(first, last):

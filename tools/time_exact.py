@@ -14,8 +14,9 @@ for cfg in cfgs:
     for name, lst in (("iterative", miba.ITERATIVE_SCHUR), ("exact", miba.DENSE_SCHUR)):
         s = miba.Solver(device_id=0)
         s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+        kw = {"pcg_check_every": int(os.environ["CHECK_EVERY"])} if "CHECK_EVERY" in os.environ else {}
         opt = miba.default_options(linear_solver_type=lst, max_num_iterations=20, function_tolerance=0.0,
-                                   parameter_tolerance=0.0, gradient_tolerance=0.0)
+                                   parameter_tolerance=0.0, gradient_tolerance=0.0, **kw)
         s.solve(miba.default_options(linear_solver_type=lst, max_num_iterations=2))   # warm-up (allocations, first launches)
         s.set_state(cams0, pts0)
         t0 = time.perf_counter()
