@@ -170,7 +170,9 @@ struct miba_handle_s {
   int32_t n_giant = 0;
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   int n_cu = 1, dev_share = 1;                    // compute units of the device; ranks of this process that share it
-  int tail_nb = 1, tail_cpw = 7;                  // grid of pcg_tail: resident as a whole (it holds grid barriers); cameras per wave
+  int tail_nb = 1, tail_n_vw = 0;                 // grid of pcg_tail: resident as a whole (it holds grid barriers); wave records
+  int32_t* d_tail_rec = nullptr;                  // [tail_n_vw][kTailRec] camera ranges of the tail's waves
+  long long* d_tail_dbg = nullptr;                // MIBA_TAIL_DEBUG=1: phase time stamps of the tail's workgroups
   unsigned* d_bar = nullptr;                      // barrier counter of pcg_tail
   bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
   int cam_model = 0;                              // MIBA_MODEL_*: camera model of the problem (miba_problem.camera_model)
@@ -749,8 +751,8 @@ int pcg_solve_mf(miba_handle h, double q_tol, int min_it, int max_it, int check_
   const bool multi = multi_rank(h);
   TailArgs A{};
   A.n_cam = h->n_cam;
-  A.cpw = h->tail_cpw;
-  A.cam_row_off = h->d_cam_row_off; A.slab = h->d_slab9; A.ct = h->d_ct; A.cm = h->d_cm; A.sc = h->d_sc; A.d2 = h->d_Dc2;
+  A.wave_rec = h->d_tail_rec; A.n_vw = h->tail_n_vw;
+  A.slab = h->d_slab9; A.ct = h->d_ct; A.cm = h->d_cm; A.sc = h->d_sc; A.d2 = h->d_Dc2;
   A.diag_w = h->cfg.rank == 0 ? 1.0 : 0.0;
   A.p = h->d_pp; A.q = h->d_pq; A.b = h->d_rhs; A.Minv = h->d_Minv; A.x = h->d_px; A.r = h->d_pr; A.z = h->d_pz;
   A.ctl = h->d_ctl;
@@ -760,7 +762,8 @@ int pcg_solve_mf(miba_handle h, double q_tol, int min_it, int max_it, int check_
   A.part_q = part_q; A.part_rho0 = part_rho[0]; A.part_rho1 = part_rho[1];
   A.q_tol = q_tol; A.min_it = min_it; A.max_it = max_it;
   A.bar = h->d_bar;
-  HIPCHK(h, hipMemsetAsync(h->d_bar, 0, sizeof(unsigned), h->st));
+  A.dbg = h->d_tail_dbg;
+  HIPCHK(h, hipMemsetAsync(h->d_bar, 0, kBarWords * sizeof(unsigned), h->st));
   hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
                      part_nb, part_rho[1]);
   hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_nb, nb, h->d_ctl);
@@ -812,6 +815,19 @@ int pcg_solve_mf(miba_handle h, double q_tol, int min_it, int max_it, int check_
       HIPCHK(h, hipEventSynchronize(h->ev_poll));
       if (h->h_ctl->done) break;
       if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
+    }
+  }
+  if (A.dbg) {   // phase time stamps of the last tail launch that went through all phases: spread over the workgroups
+    std::vector<long long> st(8 * (size_t)h->tail_nb);
+    (void)hipMemcpy(st.data(), A.dbg, st.size() * 8, hipMemcpyDeviceToHost);
+    long long t0 = st[0];
+    for (int b = 0; b < h->tail_nb; ++b) t0 = std::min(t0, st[b * 8]);
+    fprintf(stderr, "pcg_tail stamps (10 ns ticks, min..max over %d workgroups): ", h->tail_nb);
+    const char* nm[6] = {"start", "A done", "barrier 1", "scalars", "B done", "barrier 2"};
+    for (int n = 0; n < 6; ++n) {
+      long long lo = 1LL << 60, hi = -(1LL << 60);
+      for (int b = 0; b < h->tail_nb; ++b) { lo = std::min(lo, st[b * 8 + n] - t0); hi = std::max(hi, st[b * 8 + n] - t0); }
+      fprintf(stderr, "%s %lld..%lld%s", nm[n], lo, hi, n < 5 ? ", " : "\n");
     }
   }
   if (h->h_ctl->fail & 16) return fail(h, MIBA_ERR_HIP, "the PCG tail kernel's grid barrier timed out (its grid was not resident as a whole)");
@@ -1798,7 +1814,6 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   // the tail kernel of a PCG iteration holds grid barriers: its grid must be resident as a whole.  One 1024-thread workgroup per
   // compute unit at most; ranks of this process that share the device share its compute units.
   h->tail_nb = std::max(1, std::min(nblk(p->n_cam, kTailWaves), h->n_cu / std::max(1, h->dev_share)));
-  h->tail_cpw = std::max(1, std::min(7, nblk(p->n_cam, h->tail_nb * kTailWaves)));
   h->t0 = P.shard_tile[h->cfg.rank];
   h->t1 = P.shard_tile[h->cfg.rank + 1];
   h->n_tiles = h->t1 - h->t0;
@@ -1828,6 +1843,29 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   {
     std::vector<int32_t> cur(cam_row_off.begin(), cam_row_off.end() - 1);
     for (int64_t e = 0; e < n_rows; ++e) slab_row[e] = cur[P.tile_cams[tc0 + e]]++;
+  }
+  // camera ranges of the waves of pcg_tail (miba_pcg.hpp): consecutive cameras, at most seven, cut where the slab rows of the
+  // range reach the target that gives every wave of the grid the same share; the target grows until one round of the grid takes
+  // all ranges, if the seven-camera limit allows that at all
+  std::vector<int32_t> tail_rec;
+  {
+    const int W = h->tail_nb * kTailWaves;
+    const int64_t total = cam_row_off[p->n_cam];
+    int64_t target = std::max<int64_t>(1, (total + W - 1) / W);
+    for (int attempt = 0; attempt < 64; ++attempt) {
+      tail_rec.clear();
+      for (int c0 = 0; c0 < p->n_cam;) {
+        int nc = 1;
+        while (nc < 7 && c0 + nc < p->n_cam && cam_row_off[c0 + nc + 1] - cam_row_off[c0] <= target) ++nc;
+        tail_rec.push_back(c0); tail_rec.push_back(nc);
+        for (int q = 0; q < 8; ++q) tail_rec.push_back(cam_row_off[c0 + std::min(q, nc)]);
+        tail_rec.push_back(0); tail_rec.push_back(0);
+        c0 += nc;
+      }
+      if ((int64_t)tail_rec.size() / kTailRec <= W || (int64_t)nblk(p->n_cam, 7) > W) break;
+      target += std::max<int64_t>(1, target / 8);
+    }
+    h->tail_n_vw = (int)(tail_rec.size() / kTailRec);
   }
   // observations in chunk-SoA order, point ranges
   std::vector<double> oxy(dev_repack ? (size_t)1 : (size_t)(h->n_slots ? h->n_slots : 1) * 2, 0.0);
@@ -1920,6 +1958,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   const size_t nc = (size_t)p->n_cam, np = (size_t)h->n_pt, ns = (size_t)h->n_slots, nt = (size_t)h->n_tiles;
   ALLOC(h->d_tiles, nt); ALLOC(h->d_grps, grps.size());
   ALLOC(h->d_idx, ns); ALLOC(h->d_ocam, ns); ALLOC(h->d_tile_cams, n_rows); ALLOC(h->d_slab_row, n_rows);
+  ALLOC(h->d_tail_rec, tail_rec.size());
   ALLOC(h->d_cam_row_off, nc + 1); ALLOC(h->d_pt_rng, np); ALLOC(h->d_cam_active, nc); ALLOC(h->d_wl, wlv.size());
   ALLOC(h->d_oxy, 2 * ns);
   ALLOC(h->d_cam, 9 * nc); ALLOC(h->d_cam_cand, 9 * nc); ALLOC(h->d_ct, (size_t)kCamTabStride * nc); ALLOC(h->d_sc, 9 * nc);
@@ -1948,7 +1987,9 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   ALLOC(h->d_part_pcg, 5 * (size_t)kPcgMaxBlocks);
   ALLOC(h->d_sum, S_COUNT); ALLOC(h->d_max, S_COUNT);
   ALLOC(h->d_ctl, 2);
-  ALLOC(h->d_bar, 64);
+  ALLOC(h->d_bar, kBarWords);
+  h->d_tail_dbg = nullptr;
+  if (getenv("MIBA_TAIL_DEBUG")) { ALLOC(h->d_tail_dbg, 8 * (size_t)h->tail_nb); HIPCHK(h, hipMemset(h->d_tail_dbg, 0, 64 * (size_t)h->tail_nb)); }
   UP(h->d_tiles, tiles.data(), nt);
   UP(h->d_grps, grps.data(), grps.size());
   UP(h->d_idx, P.idx.data() + h->slot_base, ns);
@@ -1956,6 +1997,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   UP(h->d_tile_cams, P.tile_cams.data() + tc0, n_rows);
   UP(h->d_slab_row, slab_row.data(), n_rows);
   UP(h->d_cam_row_off, cam_row_off.data(), nc + 1);
+  UP(h->d_tail_rec, tail_rec.data(), tail_rec.size());
   UP(h->d_pt_rng, pt_rng.data(), np);
   UP(h->d_wl, wlv.data(), wlv.size());
   UP(h->d_cam_active, P.cam_active.data(), nc);

@@ -26,7 +26,7 @@ namespace miba {
 constexpr int kTailThreads = 1024;
 constexpr int kTailWaves = kTailThreads / 64;
 constexpr int kTailCams = 7 * kTailWaves;   // cameras per workgroup round: 7 per wave, nine lanes each
-constexpr int kTailBatch = 12;              // slab loads in flight per lane (84 rows per wave and batch)
+constexpr int kTailBatch = 16;              // slab loads in flight per lane (112 rows per wave and batch)
 
 // sum over the 1024-thread workgroup, the same value in every thread; s16: 16 doubles of LDS
 __device__ __forceinline__ double tail_block_sum(double v, double* s16) {
@@ -50,19 +50,28 @@ __device__ __forceinline__ double tail_sum_partials(const double* part, int n, d
   return tail_block_sum(v, s16);
 }
 
-// All workgroups of the grid meet.  count only grows (the host clears it before a solve): arrival number a belongs to barrier
-// a / n_blocks.  Thread 0 is also the thread that has stored the workgroup's partial sums: it waits for those stores to be
-// acknowledged (workgroup-scope release = s_waitcnt, no cache maintenance) before it arrives.  Returns false when the others
-// did not arrive in time.
-__device__ __forceinline__ bool tail_grid_barrier(unsigned* count, unsigned n_blocks, int* s_ok) {
+// All workgroups of the grid meet.  Two levels of counters that only grow (the host clears them before a solve): sixteen
+// workgroups share a group counter, the last of them to arrive adds one to the top counter, everybody waits for the top
+// counter to reach the number of groups times the number of barriers so far.  (Arrivals on ONE counter cost 12 ns each, one
+// after the other: 3.6 us for 256 workgroups in the microbenchmark, 4.5-6 us inside this kernel; the group counters sit in
+// different cache lines and take their arrivals side by side.)  Thread 0 is also the thread that has stored the workgroup's
+// partial sums: it waits for those stores to be acknowledged (workgroup-scope release = s_waitcnt, no cache maintenance) before
+// it arrives.  Returns false when the others did not arrive in time.
+constexpr int kBarGroup = 16;
+constexpr int kBarStride = 32;   // unsigneds between counters (128 bytes)
+__device__ __forceinline__ bool tail_grid_barrier(unsigned* bar, unsigned n_blocks, int* s_ok) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = (old / n_blocks + 1u) * n_blocks;
+    const unsigned g = blockIdx.x / kBarGroup, n_groups = (n_blocks + kBarGroup - 1) / kBarGroup;
+    const unsigned size_g = min((unsigned)kBarGroup, n_blocks - g * kBarGroup);
+    const unsigned old = __hip_atomic_fetch_add(bar + (1 + g) * kBarStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned round = old / size_g;   // barriers this group has completed before
+    if (old % size_g == size_g - 1) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (round + 1u) * n_groups;
     const long long t0 = wall_clock64();
     int ok = 1;
-    while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t0 > 200000000ll) { ok = 0; break; }   // 2 s of the 100 MHz counter
     }
@@ -71,6 +80,7 @@ __device__ __forceinline__ bool tail_grid_barrier(unsigned* count, unsigned n_bl
   __syncthreads();
   return *s_ok != 0;
 }
+constexpr int kBarWords = (1 + 64) * kBarStride;   // top counter + up to 64 groups (1024 workgroups)
 
 // Camera-side transforms of the summed raw slab row (v0..v5 = its rotation and translation parts, own = entry k) as seven
 // coefficients per lane, r = c0 v0 + ... + c5 v5 + c6 own, loaded BEFORE the rows are summed so that nothing waits on memory
@@ -104,12 +114,17 @@ __device__ __forceinline__ void tail_timed_out(Ctl* ctl) {
   for (int b = 0; b < 2; ++b) { ctl[b].done = 1; ctl[b].status = 2; ctl[b].fail |= 16; }
 }
 
+// Which cameras a wave takes (built on the host when the problem is set): consecutive cameras, at most seven, cut so that the
+// waves have about the same number of slab rows.  Record: {first camera, number of cameras, first slab row of camera 0..7 (the
+// entries past the last camera repeat its end), 0, 0}: everything phase A needs to address its rows in ONE load.
+constexpr int kTailRec = 12;
+
 struct TailArgs {
   int j;            // PCG iteration (1-based) this launch completes
   int n_cam;
-  int cpw;          // cameras per wave and round, 1..7 (nine lanes each)
+  const int32_t* wave_rec; int n_vw;   // camera ranges of the waves (kTailRec ints each, see below) and their number
   // camera-side sum (phase A)
-  const int32_t* cam_row_off; const double* slab; const double* ct; const double* cm; const double* sc; const double* d2;
+  const double* slab; const double* ct; const double* cm; const double* sc; const double* d2;
   double diag_w;
   // vectors
   double* p; double* q; const double* b; const double* Minv; double* x; double* r; double* z;
@@ -119,8 +134,10 @@ struct TailArgs {
   double* part_q;      // partials of Q, one per workgroup
   double* part_rho0; double* part_rho1;   // partials of rho_k in part_rho[k & 1]
   double q_tol; int min_it, max_it;
-  unsigned* bar;       // barrier counter
+  unsigned* bar;       // barrier counters
+  long long* dbg;      // MIBA_TAIL_DEBUG: [workgroup][8] time stamps of the phases (100 MHz counter), else null
 };
+#define TAIL_STAMP(n) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + n] = wall_clock64(); } while (0)
 
 // two partial-sum arrays in one pass (one trip to memory instead of two)
 __device__ __forceinline__ void tail_sum_partials2(const double* pa, int na, const double* pb, int nb, double* s32, double& sa, double& sb) {
@@ -157,18 +174,22 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   __shared__ int s_bnd[kTailWaves * 8];
   __shared__ double s_wp[REDUCE ? kTailWaves * 7 * 64 : 1];
   const int j = a.j;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sub = lane / 9, k = lane - 9 * sub;
+  const int nb = gridDim.x;
+  // wave records vw0, vw0 + n_waves, ...: consecutive records go to different workgroups, so that every workgroup has work
+  // when there are fewer records than waves
+  const int vw0 = wv * nb + blockIdx.x, n_waves = nb * kTailWaves;
+  const bool single = a.n_vw <= n_waves;   // one round: values are carried in registers
+  // the first record is fetched together with the control block (one trip to memory instead of two)
+  const int rec_first = (vw0 < a.n_vw) ? a.wave_rec[(size_t)kTailRec * vw0 + min(lane, kTailRec - 1)] : 0;
   Ctl c = a.ctl[(j - 1) & 1];   // C_{j-1}
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   if (c.done) {
     if (writer && MODE != 1) a.ctl[j & 1] = c;   // the final state in both buffers
     return;
   }
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int sub = lane / 9, k = lane - 9 * sub;
-  const int nb = gridDim.x;
-  const int wave_first = (blockIdx.x * kTailWaves + wv) * a.cpw, stride = nb * kTailWaves * a.cpw;
-  const bool single = stride >= a.n_cam;   // one round: values are carried in registers
-  const bool lane_on = sub < a.cpw;
+  TAIL_STAMP(0);
   double* part_rho_cur = (j & 1) ? a.part_rho1 : a.part_rho0;
   double* part_rho_next = (j & 1) ? a.part_rho0 : a.part_rho1;
   // carried through the phases when single (entry k of the lane's camera)
@@ -182,30 +203,21 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
     double xy = 0.0;
     double* wp = s_wp + (size_t)wv * 7 * 64;
     int* bnd = s_bnd + wv * 8;
-    for (int cam0 = wave_first; cam0 < a.n_cam; cam0 += stride) {
-      const int ncw = min(a.cpw, a.n_cam - cam0);
+    for (int vw = vw0; vw < a.n_vw; vw += n_waves) {
+      const int rec = (vw == vw0) ? rec_first : a.wave_rec[(size_t)kTailRec * vw + min(lane, kTailRec - 1)];
+      const int cam0 = __shfl(rec, 0, 64), ncw = __shfl(rec, 1, 64);
       const bool on = sub < ncw;
       const int cam = on ? cam0 + sub : cam0;
       const size_t i = 9 * (size_t)cam + k;
-      const int bl = a.cam_row_off[cam0 + min(lane, ncw)];
       const double xv = on ? v_in[i] : 0.0;
       const double scv = on ? a.sc[i] : 0.0, d2v = on ? a.d2[i] : 0.0;
       double cf[7];
       tail_cam_coef(k, a.ct + (size_t)kCamTabStride * cam, a.cm + 10 * (size_t)cam, cf);
-      if (single && on) {
-        if (MODE != 2) { c_p = xv; c_x = a.x[i]; } else c_x = xv;
-        if (MODE != 1) {
-          c_b = a.b[i];
-          if (MODE == 0) c_r = a.r[i];
-#pragma unroll
-          for (int m = 0; m < 9; ++m) c_M[m] = a.Minv[81 * (size_t)cam + 9 * m + k];
-        }
-      }
-      if (lane < 8) bnd[lane] = bl;
+      if (lane >= 2 && lane < 10) bnd[lane - 2] = rec;
 #pragma unroll
       for (int q7 = 0; q7 < 7; ++q7) wp[q7 * 64 + lane] = 0.0;
       __builtin_amdgcn_wave_barrier();
-      const int R0 = __shfl(bl, 0, 64), R1 = __shfl(bl, ncw, 64);
+      const int R0 = __shfl(rec, 2, 64), R1 = __shfl(rec, 2 + ncw, 64);
       int cj = 0, b_next = bnd[1];
       double acc = 0.0;
       const double* sp = a.slab + k;
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
         double rr = cf[0] * v0 + cf[1] * v1 + cf[2] * v2 + cf[3] * v3 + cf[4] * v4 + cf[5] * v5 + cf[6] * tot;
         rr *= scv;
         rr += a.diag_w * d2v * xv;
-        if (single) c_q = rr;
+        if (single) { c_q = rr; if (MODE != 2) c_p = xv; else c_x = xv; }
         else a.q[i] = rr;
         xy += xv * rr;
       }
@@ -254,35 +266,56 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
     if (MODE != 2) {
       const double s = tail_block_sum(xy, s32);
       if (tid == 0) tail_put(a.part_pq + blockIdx.x, s);
+      TAIL_STAMP(1);
       if (!tail_grid_barrier(a.bar, nb, &s_ok)) {
         if (writer) tail_timed_out(a.ctl);
         return;
       }
+      TAIL_STAMP(2);
     }
   }
 
   // ---- B: alpha and the vector updates ----
+  // single: the lane's entries of the vectors and its row of M^-1 are requested BEFORE the partial sums, so that they arrive
+  // with them (loads return in order): nothing is waited for twice
+  const int cam0_1 = __shfl(rec_first, 0, 64), ncw_1 = __shfl(rec_first, 1, 64);
+  if (single && sub < ncw_1 && vw0 < a.n_vw) {
+    const size_t i = 9 * (size_t)(cam0_1 + sub) + k;
+    if (!REDUCE) { c_q = a.q[i]; c_p = a.p[i]; c_x = a.x[i]; }
+    else if (MODE != 2) c_x = a.x[i];
+    if (MODE != 1) {
+      c_b = a.b[i];
+      if (MODE == 0) c_r = a.r[i];
+#pragma unroll
+      for (int m = 0; m < 9; ++m) c_M[m] = a.Minv[81 * (size_t)(cam0_1 + sub) + 9 * m + k];
+    }
+  }
   const int n_pq = REDUCE ? nb : a.n_pq;
   double rho, pq;
   tail_sum_partials2(part_rho_cur, nb, a.part_pq, n_pq, s32, rho, pq);
   const bool pq_bad = pq <= 0.0 || isinf(pq) || isnan(pq);
   const double alpha = rho / pq;
   const bool alpha_bad = !pq_bad && isinf(alpha);
-  const bool carried = REDUCE && single;
+  TAIL_STAMP(3);
   if (!pq_bad && !alpha_bad) {
     double a_q = 0.0, a_rho = 0.0;
-    for (int cam0 = wave_first; cam0 < a.n_cam; cam0 += stride) {
-      const bool on = lane_on && cam0 + sub < a.n_cam;
+    for (int vw = vw0; vw < a.n_vw; vw += n_waves) {
+      int cam0 = cam0_1, ncw = ncw_1;
+      if (vw != vw0) {
+        const int rec = a.wave_rec[(size_t)kTailRec * vw + (lane & 1)];
+        cam0 = __shfl(rec, 0, 64); ncw = __shfl(rec, 1, 64);
+      }
+      const bool on = sub < ncw;
       const int cam = on ? cam0 + sub : cam0;
       const size_t i = 9 * (size_t)cam + k;
       double rv = 0.0, xv = 0.0;
       if (on) {
-        if (MODE == 2) xv = carried ? c_x : a.x[i];
-        else { xv = (carried ? c_x : a.x[i]) + alpha * (carried ? c_p : a.p[i]); a.x[i] = xv; }
+        if (MODE == 2) xv = single ? c_x : a.x[i];
+        else { xv = (single ? c_x : a.x[i]) + alpha * (single ? c_p : a.p[i]); a.x[i] = xv; }
         if (MODE != 1) {
-          const double bv = carried ? c_b : a.b[i];
-          const double qv = carried ? c_q : a.q[i];
-          rv = (MODE == 0) ? (carried ? c_r : a.r[i]) - alpha * qv : bv - qv;
+          const double bv = single ? c_b : a.b[i];
+          const double qv = single ? c_q : a.q[i];
+          rv = (MODE == 0) ? (single ? c_r : a.r[i]) - alpha * qv : bv - qv;
           a.r[i] = rv;
           a_q += xv * (bv + rv);
         }
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
         double zz = 0.0;
 #pragma unroll
         for (int m = 0; m < 9; ++m) {
-          const double mv = carried ? c_M[m] : (on ? a.Minv[81 * (size_t)cam + 9 * m + k] : 0.0);
+          const double mv = single ? c_M[m] : (on ? a.Minv[81 * (size_t)cam + 9 * m + k] : 0.0);
           zz += mv * __shfl(rv, 9 * sub + m, 64);
         }
         if (on) {
@@ -317,12 +350,16 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
     }
   }
   if (MODE == 1) return;
+  TAIL_STAMP(4);
   if (!tail_grid_barrier(a.bar, nb, &s_ok)) {
     if (writer) tail_timed_out(a.ctl);
     return;
   }
+  TAIL_STAMP(5);
 
   // ---- C: end of iteration j, direction of iteration j + 1 (pcg_chkdir(j + 1)) ----
+  // (a single-round MODE 2 has not had p in its registers: requested before the partial sums, like the vectors of phase B)
+  if (single && MODE == 2 && REDUCE && sub < ncw_1 && vw0 < a.n_vw) c_p = a.p[9 * (size_t)(cam0_1 + sub) + k];
   double qs = 0.0, rho_n = 0.0;
   if (!pq_bad && !alpha_bad) tail_sum_partials2(a.part_q, nb, part_rho_next, nb, s32, qs, rho_n);
   c.n_it = j;
@@ -359,14 +396,18 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   if (bad) { c.done = 1; c.status = 2; c.n_it = j + 1; }
   if (writer) a.ctl[j & 1] = c;
   if (bad) return;
-  for (int cam0 = wave_first; cam0 < a.n_cam; cam0 += stride) {
-    if (lane_on && cam0 + sub < a.n_cam) {
+  for (int vw = vw0; vw < a.n_vw; vw += n_waves) {
+    int cam0 = cam0_1, ncw = ncw_1;
+    if (vw != vw0) {
+      const int rec = a.wave_rec[(size_t)kTailRec * vw + (lane & 1)];
+      cam0 = __shfl(rec, 0, 64); ncw = __shfl(rec, 1, 64);
+    }
+    if (sub < ncw) {
       const size_t i = 9 * (size_t)(cam0 + sub) + k;
-      // MODE 2 has carried x as the product's input, not p
-      const double pv = (carried && MODE == 0) ? c_p : a.p[i];
-      a.p[i] = (carried ? c_z : a.z[i]) + beta * pv;
+      a.p[i] = (single ? c_z : a.z[i]) + beta * (single ? c_p : a.p[i]);
     }
   }
+  TAIL_STAMP(6);
 }
 
 }  // namespace miba
