@@ -13,8 +13,9 @@ for p in paths:
             name = re.sub(r"^void ", "", row.get("Kernel_Name", ""))
             name = re.sub(r"^miba::", "", name).split("(")[0]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-res = {"source": "rocprofv3 --pmc passes over tools/time_k3.py final-13682 (final round-1 build, default tiles), means per "
-                 "dispatch; merged by tools/pmc_to_json.py (units in its docstring)"}
+import os
+res = {"source": os.environ.get("PMC_SOURCE", "rocprofv3 --pmc passes over tools/time_k3.py final-13682 (default tiles)") +
+                 ", means per dispatch; merged by tools/pmc_to_json.py (units in its docstring)"}
 for name, cs in sorted(acc.items()):
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     d = dict(m)

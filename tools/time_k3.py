@@ -10,7 +10,8 @@ cams0, pts0 = synth.perturb(pr, 1e-3, 0.05, seed=seed + 1)
 s = miba.Solver(device_id=0)
 s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
 probe = np.random.default_rng(1).normal(size=(n_cam, 9))
-out = s.linear_step(1e4, miba.default_options(max_linear_solver_iterations=2), probe=probe)
+# (PCG_ITS iterations of the PCG: 12 take in a residual-reset iteration, so every instance of pcg_tail runs under the counters)
+out = s.linear_step(1e4, miba.default_options(max_linear_solver_iterations=int(os.environ.get("PCG_ITS", "2")), eta=1e-30), probe=probe)
 ms = [s.time_matvec(probe, reps) for _ in range(3)]
 kt = s.kernel_times()
 print(json.dumps({"mf": os.environ.get("MIBA_MF", "0"), "tile_chunks": os.environ.get("MIBA_TILE_CHUNKS", "4"), "matvec_ms": ms,
