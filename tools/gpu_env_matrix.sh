@@ -3,11 +3,14 @@
 set -o pipefail
 run() { echo "== $*"; env "$@" timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread $EXTRA 2>&1 | tail -2 || exit 1; }
 EXTRA=""
+if [ -z "$SKIP_TILE_CHUNKS" ]; then
 run MIBA_TILE_CHUNKS=1 || exit 1
 run MIBA_TILE_CHUNKS=16 || exit 1
+fi
 run MIBA_POINT_ORDER=0 || exit 1
 run MIBA_FORCE_RCCL=1 || exit 1
 run MIBA_DENSE_PLAN=0 || exit 1
+run MIBA_DEVICE_PLAN=0 || exit 1
 # the exact solve and SCHUR_JACOBI need the two-pass matrix-free kernels: the tests that use them are skipped for these three
 # (so do the loss functions: tests/test_gpu_loss.py is left out for the first two)
 EXTRA="--deselect tests/test_gpu_dense.py --deselect tests/test_gpu_multirank.py --deselect tests/test_gpu_loss.py"
