@@ -168,23 +168,15 @@ def main():
     kt = solver.kernel_times()
 
     n_cg = sum(r["linear_solver_iterations"] for r in timed)
-    mf = os.environ.get("MIBA_MF", "1") != "0"
     # Algorithmic bytes per launch, exactly as DESIGN.md section 4 lists them: o = this rank's observations, m = its points,
     # n = cameras.  Matrix-free kernels read a 4-byte index word per observation (+ the 16-byte measurement where the
     # residual is needed), point blocks per point and camera vectors in and out.
     o_loc, m_loc = kt["n_obs_local"], kt["n_pt_local"]
-    if mf:
-        alg = {miba.K_EVAL_COST: ("K1p_mf_cost", 20.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
-               miba.K_SCHUR_INIT: ("K2a_mf_init_points", 20.0 * o_loc + 168.0 * m_loc),
-               miba.K_SCHUR_INIT_CAM: ("K2b_mf_camrows", 20.0 * o_loc + 48.0 * m_loc + 584.0 * n_cam),
-               miba.K_SCHUR_MATVEC: ("K3_mf_matvec", 4.0 * o_loc + 72.0 * m_loc + 144.0 * n_cam),
-               miba.K_BACKSUB: ("K4_mf_backsub", 20.0 * o_loc + 168.0 * m_loc + 72.0 * n_cam)}
-    else:
-        alg = {miba.K_EVAL_JAC: ("K1_eval_jac", 228.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
-               miba.K_EVAL_COST: ("K1p_eval_cost", 20.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
-               miba.K_SCHUR_INIT: ("K2_schur_init", 212.0 * o_loc + 72.0 * m_loc + 720.0 * n_cam),
-               miba.K_SCHUR_MATVEC: ("K3_schur_matvec", 196.0 * o_loc + 48.0 * m_loc + 144.0 * n_cam),
-               miba.K_BACKSUB: ("K4_backsub", 212.0 * o_loc + 96.0 * m_loc + 72.0 * n_cam)}
+    alg = {miba.K_EVAL_COST: ("K1p_mf_cost", 20.0 * o_loc + 24.0 * m_loc + 72.0 * n_cam),
+           miba.K_SCHUR_INIT: ("K2a_mf_init_points", 20.0 * o_loc + 168.0 * m_loc),
+           miba.K_SCHUR_INIT_CAM: ("K2b_mf_camrows", 20.0 * o_loc + 48.0 * m_loc + 584.0 * n_cam),
+           miba.K_SCHUR_MATVEC: ("K3_mf_matvec", 4.0 * o_loc + 72.0 * m_loc + 144.0 * n_cam),
+           miba.K_BACKSUB: ("K4_mf_backsub", 20.0 * o_loc + 168.0 * m_loc + 72.0 * n_cam)}
     k3_bytes = alg[miba.K_SCHUR_MATVEC][1]
     # Inside the PCG the library times the product in one iteration out of 8 (an event pair costs two 6 us bubbles on
     # the stream; MIBA_TIME_EVERY=1 times every launch) and keeps the launches that were enqueued ahead of the host poll
@@ -199,7 +191,7 @@ def main():
     pmc, pmc_file = {}, None
     for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", cand)
-        if mf and args.gpus == 1 and args.config == "final-13682" and os.path.exists(tpath):
+        if args.gpus == 1 and args.config == "final-13682" and os.path.exists(tpath):
             with open(tpath) as fh:
                 pmc = json.load(fh)
             pmc_file = "profiles/" + cand
@@ -233,34 +225,31 @@ def main():
                 "algorithmic_bytes_per_launch": k3_bytes,
                 "note": "4 o + 72 m + 144 n bytes per launch: the matrix-free product reads an index word per observation, "
                         "not a stored Jacobian; its arithmetic intensity (about 14 flop/byte) is past the fp64 ridge of 9.8"}
-    if mf:
-        # The matrix-free product is compute-side bound: its arithmetic intensity is past the fp64 ridge and the PMC
-        # passes show the fp64 vector pipe and the LDS pipe busy, HBM nearly idle.  The roofline it is priced against is
-        # therefore the fp64 vector peak (there is no GEMM here to put on MFMA); the HBM view is kept beside it.
-        flop = MF_FLOP_PER_SLOT * kt["n_slots"]
-        tf = flop / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
-        stored = 196.0 * o_loc + 48.0 * m_loc + 144.0 * n_cam
-        roof = {"bound": "fp64_valu+lds", "kernel": "k_mf_matvec (K3-mf)", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flop_per_launch": flop,
-                "traffic": rec3.get("traffic_bytes_per_launch"),
-                "traffic_source": (pmc_file + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of an earlier run of this kernel; "
-                                   "a constant, not collected in this run)") if pmc_file else None,
-                "avg_launch_ms": k3_ms, "launches_timed": k3_n, "launches_in_timed_steps": k3_total,
-                "timed_launches_that_returned_at_once": k3_skipped,
-                "hbm": hbm_view,
-                "stored_jacobian_form": {"bytes_per_launch": stored,
-                                         "equivalent_GBs": stored / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0,
-                                         "note": "bytes a stored-J product (SURVEY 8d: 196 o + 48 m + 144 n) streams per launch; at 8 TB/s "
-                                                 "that alone takes %.3f ms" % (stored / 8e12 * 1e3)}}
-        if rec3:
-            roof["measured_pipe_utilisation"] = {"valu_busy_frac": rec3.get("valu_busy_frac"), "lds_busy_frac": rec3.get("lds_busy_frac"),
-                                                 "waves_per_simd": rec3.get("waves_resident_per_simd"), "source": pmc_file}
-    else:
-        roof = dict(hbm_view, bound="hbm", kernel="k_schur_matvec<0> (K3)", traffic=None, avg_launch_ms=k3_ms, launches_timed=k3_n)
+    # The matrix-free product is compute-side bound: its arithmetic intensity is past the fp64 ridge and the PMC
+    # passes show the fp64 vector pipe and the LDS pipe busy, HBM nearly idle.  The roofline it is priced against is
+    # therefore the fp64 vector peak (there is no GEMM here to put on MFMA); the HBM view is kept beside it.
+    flop = MF_FLOP_PER_SLOT * kt["n_slots"]
+    tf = flop / (k3_ms * 1e-3) / 1e12 if k3_ms > 0 else 0.0
+    stored = 196.0 * o_loc + 48.0 * m_loc + 144.0 * n_cam
+    roof = {"bound": "fp64_valu+lds", "kernel": "k_mf_matvec (K3-mf)", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flop_per_launch": flop,
+            "traffic": rec3.get("traffic_bytes_per_launch"),
+            "traffic_source": (pmc_file + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of an earlier run of this kernel; "
+                               "a constant, not collected in this run)") if pmc_file else None,
+            "avg_launch_ms": k3_ms, "launches_timed": k3_n, "launches_in_timed_steps": k3_total,
+            "timed_launches_that_returned_at_once": k3_skipped,
+            "hbm": hbm_view,
+            "stored_jacobian_form": {"bytes_per_launch": stored,
+                                     "equivalent_GBs": stored / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0,
+                                     "note": "bytes a stored-J product (SURVEY 8d: 196 o + 48 m + 144 n) streams per launch; at 8 TB/s "
+                                             "that alone takes %.3f ms" % (stored / 8e12 * 1e3)}}
+    if rec3:
+        roof["measured_pipe_utilisation"] = {"valu_busy_frac": rec3.get("valu_busy_frac"), "lds_busy_frac": rec3.get("lds_busy_frac"),
+                                             "waves_per_simd": rec3.get("waves_resident_per_simd"), "source": pmc_file}
     # per-PCG-iteration cost: everything between two products (camera reduction, vector kernels, launch gaps, polls)
     t_lin = sum(r["iteration_time_in_seconds"] for r in timed)
     pcg = {"pcg_iterations": n_cg, "ms_per_pcg_iteration_all_in": 1e3 * dt / max(1, n_cg),
-           "product_ms": k3_ms, "tail_ms": red_ms, "launches_per_iteration": 2 if (mf and args.gpus == 1) else 4,
+           "product_ms": k3_ms, "tail_ms": red_ms, "launches_per_iteration": 2 if args.gpus == 1 else 4,
            "note": "all_in = timed wall time / PCG iterations (K2, K4, K1' and host reads included); product = k_mf_matvec over "
                    "the tiles, tail = pcg_tail (camera-side sum, vector updates, scalars, next direction in one launch; with "
                    "several ranks only the camera-side sum is timed here), both from HIP events on sampled iterations"}
@@ -282,7 +271,7 @@ def main():
                                "initial state = ground truth + N(0,%g) on camera rot/trans + N(0,%g) on points; "
                                "LM + ITERATIVE_SCHUR (implicit Schur, %s preconditioner, eta=%g); %s kernels%s"
                                % (args.config, n_cam, n_pt, n_obs, seed, args.sigma_cam, args.sigma_x, args.preconditioner.upper(), args.eta,
-                                  "matrix-free" if mf else "stored-Jacobian", "" if args.loss == "none" else "; loss " + args.loss),
+                                  "matrix-free", "" if args.loss == "none" else "; loss " + args.loss),
                    "pcg_iterations_in_timed_steps": n_cg,
                    "successful_steps_in_timed_steps": sum(r["step_is_successful"] for r in timed),
                    "cost_first": its[0]["cost"], "cost_last": summ["final_cost"],

@@ -166,7 +166,6 @@ struct miba_handle_s {
   double* d_slabB = nullptr;
   double* d_cfree = nullptr;                      // [n_cam][9] 1 = free, 0 = entry of a constant parameter block
   int32_t n_seg = 0;
-  bool k2_onepass = false;                        // MIBA_K2_ONEPASS=1: K2-mf with LDS-atomic camera rows in one pass
   int32_t n_giant = 0;
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   int n_cu = 1, dev_share = 1;                    // compute units of the device; ranks of this process that share it
@@ -174,14 +173,13 @@ struct miba_handle_s {
   int32_t* d_tail_rec = nullptr;                  // [tail_n_vw][kTailRec] camera ranges of the tail's waves
   long long* d_tail_dbg = nullptr;                // MIBA_TAIL_DEBUG=1: phase time stamps of the tail's workgroups
   unsigned* d_bar = nullptr;                      // barrier counter of pcg_tail
-  bool use_mf = true;                             // matrix-free K2/K3/K4 (MIBA_MF=0: stored Jacobian)
   int cam_model = 0;                              // MIBA_MODEL_*: camera model of the problem (miba_problem.camera_model)
   std::vector<double> principal;                  // model 1: (ox, oy) per camera that the uploaded observations carry
   Loss loss = {kLossNone, 1.0};                   // robust loss of the current solve (options.loss_type / loss_scale)
   double* d_omega = nullptr;                      // [n_slots] loss weights rho' of the current linearisation (loss only)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
-  double *d_Cinv = nullptr, *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
-  double *d_slab64 = nullptr, *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
+  double *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
+  double *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
   double *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pq = nullptr, *d_probe = nullptr;
   // exact reduced solve (miba_dense.hpp), allocated on first use: dense S [N + 64][N], factors of its diagonal blocks, pivot flag
   double *d_S = nullptr, *d_Linv = nullptr;
@@ -431,7 +429,7 @@ int launch_cam_tables(miba_handle h, const double* cam, bool candidate = false) 
   return MIBA_OK;
 }
 
-// the stored Jacobian (26 doubles per slot) exists only for miba_evaluate and the MIBA_MF=0 path
+// the stored Jacobian (26 doubles per slot) exists only for miba_evaluate, which hands it to the caller
 int ensure_J(miba_handle h) {
   if (h->d_J) return MIBA_OK;
   return dev_alloc(h, &h->d_J, (size_t)kJComp * (size_t)(h->n_slots ? h->n_slots : 1));
@@ -459,7 +457,7 @@ int eval_cost(miba_handle h, const double* cam, const double* X, bool reduce = t
   // candidate state: its camera table must not disturb the table of the current state (K3-mf reads it)
   int rc = launch_cam_tables(h, cam, true);
   if (rc) return rc;
-  if (h->n_tiles && h->use_mf) {
+  if (h->n_tiles) {
     Timed t(h, MIBA_K_EVAL_COST);
 #define MIBA_COST_ARGS                                                                                                   \
   dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant, h->d_grps,   \
@@ -467,18 +465,12 @@ int eval_cost(miba_handle h, const double* cam, const double* X, bool reduce = t
     if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_cost<true>, MIBA_COST_ARGS);
     else hipLaunchKernelGGL(k_mf_cost<false>, MIBA_COST_ARGS);
 #undef MIBA_COST_ARGS
-  } else if (h->n_tiles) {
-    Timed t(h, MIBA_K_EVAL_COST);
-    hipLaunchKernelGGL(k_eval<false>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
-                       h->d_ocam, h->d_oxy, h->d_ct_cand, X, nullptr, nullptr, nullptr, h->d_part_tile);
   }
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 1, 0, 0, h->d_sum + S_COST);
   HIPCHK(h, hipGetLastError());
   return reduce ? allreduce(h, h->d_sum + S_COST, 1, ncclSum) : MIBA_OK;
 }
-
-constexpr size_t kK2Lds = (size_t)(kMaxCamSlots * 63 + kChunk * 9 + kChunk * 3 + 4) * sizeof(double);
 
 // K2 + camera reductions + camera blocks; fills Cinv, gp, Minv, Dc2, rhs and the gradient norms
 // K2-mf over all tiles of this shard (camera tables of the current state must be in d_ct / d_cm):
@@ -495,36 +487,23 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want
       hipLaunchKernelGGL(k_mf_camrows<false>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
                          h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
   };
-  bool two_pass = false;
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
 #define MIBA_INIT_ARGS(list)                                                                                              \
   h->d_tiles, list, h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_oxy, h->d_ct, h->d_cm,   \
       h->d_X, h->d_sp, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_gp, want_diag ? h->d_dgp : (double*)nullptr,    \
-      h->d_ptrec, h->d_slab64, h->d_part_tile, h->d_ctl, h->loss, h->d_omega
+      h->d_ptrec, h->d_part_tile, h->d_ctl, h->loss, h->d_omega
+    // point side (wavelets); with a robust loss it leaves rho' per slot.  The camera side follows over the camera-major copy.
     if (h->loss.type != kLossNone) {
-      // robust loss (set_loss has checked that the two-pass kernels are in use): the point side leaves rho' per slot
-      hipLaunchKernelGGL((k_mf_init<false, false, true>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
-                         MIBA_INIT_ARGS((const int32_t*)nullptr));
-      if (h->n_giant)
-        hipLaunchKernelGGL((k_mf_init<true, false, true>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
-      two_pass = true;
-    } else if (h->k2_onepass) {
-      hipLaunchKernelGGL((k_mf_init<false, true, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
-                         MIBA_INIT_ARGS((const int32_t*)nullptr));
-      if (h->n_giant)
-        hipLaunchKernelGGL((k_mf_init<true, true, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
+      hipLaunchKernelGGL((k_mf_init<false, true>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS((const int32_t*)nullptr));
+      if (h->n_giant) hipLaunchKernelGGL((k_mf_init<true, true>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
     } else {
-      // point side (wavelets), then camera side over the camera-major copy of the observations
-      hipLaunchKernelGGL((k_mf_init<false, false, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st,
-                         MIBA_INIT_ARGS((const int32_t*)nullptr));
-      if (h->n_giant)
-        hipLaunchKernelGGL((k_mf_init<true, false, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
-      two_pass = true;
+      hipLaunchKernelGGL((k_mf_init<false, false>), dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS((const int32_t*)nullptr));
+      if (h->n_giant) hipLaunchKernelGGL((k_mf_init<true, false>), dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, MIBA_INIT_ARGS(h->d_giant));
     }
 #undef MIBA_INIT_ARGS
   }
-  if (two_pass) camrows();
+  if (h->n_tiles) camrows();
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 0, 0, h->d_sum + S_COST);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 1, 1, h->d_max + S_GMAX_P);
@@ -533,17 +512,15 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want
   return reduce_cost ? allreduce(h, h->d_sum + S_COST, 1, ncclSum) : MIBA_OK;
 }
 
-// camera sums of K2: rows of the tile slab (stored-J / one-pass K2-mf) or of the segment slab (two-pass K2-mf)
+// camera sums of K2: rows of the segment slab the camera pass has left
 int cam_reduce64(miba_handle h, const double* sc) {
-  const bool segs = h->use_mf && !h->k2_onepass;
-  hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam,
-                     segs ? h->d_cam_seg_off : h->d_cam_row_off, segs ? h->d_slabB : h->d_slab64, sc, h->d_camacc);
+  hipLaunchKernelGGL(k_cam_reduce64, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_seg_off, h->d_slabB, sc, h->d_camacc);
   HIPCHK(h, hipGetLastError());
   return MIBA_OK;
 }
 
 // robust loss of this solve: validated, kept in the handle for the kernel launches; the weight array is allocated on
-// first use.  The loss lives in the two-pass matrix-free kernels only.
+// first use.
 int set_loss(miba_handle h, const miba_options* o) {
   if (o->loss_type == MIBA_LOSS_NONE) {
     h->loss = Loss{kLossNone, 1.0};
@@ -551,8 +528,6 @@ int set_loss(miba_handle h, const miba_options* o) {
   }
   if (o->loss_type != MIBA_LOSS_HUBER && o->loss_type != MIBA_LOSS_CAUCHY) return fail(h, MIBA_ERR_INVALID, "unknown loss_type %d", (int)o->loss_type);
   if (!(o->loss_scale > 0.0) || !std::isfinite(o->loss_scale)) return fail(h, MIBA_ERR_INVALID, "loss_scale must be positive and finite");
-  if (!h->use_mf || h->k2_onepass)
-    return fail(h, MIBA_ERR_INVALID, "a loss function needs the two-pass matrix-free kernels (MIBA_MF=0 or MIBA_K2_ONEPASS=1 is set)");
   if (!h->d_omega) {
     int rc = dev_alloc(h, &h->d_omega, h->n_slots ? h->n_slots : 1);
     if (rc) return rc;
@@ -568,18 +543,10 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   // With several ranks the three scalars of this stage (cost, |g_p|^2, max |g_p|) ride in the unused 64th entry of
   // the camera sums (cameras 0, 1 and 2 + rank: one slot per rank turns the max into a sum), so the stage costs ONE
   // all-reduce instead of four.
-  const bool pack = h->use_mf && multi_rank(h) && h->n_cam >= 2 + h->cfg.world_size;
-  if (h->use_mf) {
-    rc = mf_init_launch(h, inv_r, o, false, !pack);
-    if (rc) return rc;
-  } else if (h->n_tiles) {
-    Timed t(h, MIBA_K_SCHUR_INIT);
-    hipLaunchKernelGGL(k_schur_init, dim3((unsigned)h->n_tiles), dim3(kChunk), kK2Lds, h->st, h->d_tiles, h->d_grps, h->d_idx,
-                       h->d_pt_rng, h->d_slab_row, h->d_J, inv_r, o->min_lm_diagonal, o->max_lm_diagonal, h->d_Cinv, h->d_gp,
-                       h->d_dgp, h->d_slab64, h->d_ctl, h->d_X, h->d_sp, h->d_ptrec);
-  }
-  HIPCHK(h, hipGetLastError());
-  rc = cam_reduce64(h, h->use_mf ? h->d_sc : (const double*)nullptr);
+  const bool pack = multi_rank(h) && h->n_cam >= 2 + h->cfg.world_size;
+  rc = mf_init_launch(h, inv_r, o, false, !pack);
+  if (rc) return rc;
+  rc = cam_reduce64(h, h->d_sc);
   if (rc) return rc;
   if (pack) hipLaunchKernelGGL(k_pack_scalars, dim3(1), dim3(64), 0, h->st, h->d_camacc, h->d_sum, h->d_max, h->cfg.rank, 0, h->cfg.world_size);
   rc = allreduce(h, h->d_camacc, (size_t)kK2W * h->n_cam, ncclSum);
@@ -589,8 +556,6 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   const double* acc2 = nullptr;
   if (o->preconditioner_type == MIBA_PRECOND_SCHUR_JACOBI && o->linear_solver_type == MIBA_ITERATIVE_SCHUR) {
     // block diagonal of S itself: one more camera-major pass for sum G'WG (needs the point records K2 has just written)
-    if (!h->use_mf || h->k2_onepass)
-      return fail(h, MIBA_ERR_INVALID, "preconditioner SCHUR_JACOBI needs the two-pass matrix-free kernels (MIBA_MF=0 or MIBA_K2_ONEPASS=1 is set)");
     if (!h->d_camacc2) {
       rc = dev_alloc(h, &h->d_camacc2, (size_t)kK2W * h->n_cam);
       if (rc) return rc;
@@ -615,15 +580,7 @@ int schur_init(miba_handle h, double radius, const miba_options* o) {
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 0, 1, h->d_max + S_GMAX_C);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 1, 0, h->d_sum + S_G2_C);
   HIPCHK(h, hipGetLastError());
-  // point gradient norms (local points; the matrix-free K2 has already left them), then all-reduce
-  if (!h->use_mf) {
-    const int nbp = 240;
-    double* pp = h->d_part_small + 2 * (size_t)nb;
-    hipLaunchKernelGGL(k_pt_gradnorm, dim3(nbp), dim3(256), 0, h->st, h->n_pt, h->d_gp, h->d_sp, pp);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 0, 1, h->d_max + S_GMAX_P);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, pp, (size_t)nbp, 2, 1, 0, h->d_sum + S_G2_P);
-  }
-  HIPCHK(h, hipGetLastError());
+  // point gradient norms: K2 has left them for the local points; all-reduce
   if (pack) return MIBA_OK;
   rc = allreduce(h, h->d_sum + S_G2_P, 1, ncclSum);
   if (rc) return rc;
@@ -650,29 +607,18 @@ void mf_matvec_tiles(miba_handle h, const double* x, Ctl* ctl, int pcg_iter, boo
 
 int schur_matvec(miba_handle h, const double* x, double* y, Ctl* ctl, double* part_xy, int pcg_iter = 0) {
   const bool sample = pcg_iter <= 0 || (pcg_iter - 1) % h->time_every == 0;
-  if (h->use_mf) {
-    mf_matvec_tiles(h, x, ctl, pcg_iter, sample);
-    {
-      Timed t(h, MIBA_K_CAM_REDUCE, pcg_iter, sample && pcg_iter > 0);
-      hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
-                         h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, part_xy, ctl);
-    }
-    HIPCHK(h, hipGetLastError());
-    // x.y is linear in y, so with several ranks the per-block partials of x.y_local are all-reduced together with
-    // y_local (the caller places them right behind y): every rank then sums the same red_nb numbers
-    const bool tail = part_xy && part_xy == y + 9 * (size_t)h->n_cam;
-    if (multi_rank(h) && part_xy && !tail) return fail(h, MIBA_ERR_INVALID, "x.y partials must follow y for the all-reduce");
-    return allreduce(h, y, 9 * (size_t)h->n_cam + (tail ? (size_t)h->red_nb : 0), ncclSum);
+  mf_matvec_tiles(h, x, ctl, pcg_iter, sample);
+  {
+    Timed t(h, MIBA_K_CAM_REDUCE, pcg_iter, sample && pcg_iter > 0);
+    hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
+                       h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, part_xy, ctl);
   }
-  if (h->n_tiles) {
-    Timed t(h, MIBA_K_SCHUR_MATVEC, pcg_iter, sample);
-    hipLaunchKernelGGL(k_schur_matvec<0>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
-                       h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_J, h->d_Cinv, x, h->d_slab9, nullptr, ctl);
-  }
-  hipLaunchKernelGGL(k_cam_reduce9, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
-                     h->d_Dc2, x, h->cfg.rank == 0 ? 1.0 : 0.0, y, ctl);
   HIPCHK(h, hipGetLastError());
-  return allreduce(h, y, 9 * (size_t)h->n_cam, ncclSum);
+  // x.y is linear in y, so with several ranks the per-block partials of x.y_local are all-reduced together with
+  // y_local (the caller places them right behind y): every rank then sums the same red_nb numbers
+  const bool tail = part_xy && part_xy == y + 9 * (size_t)h->n_cam;
+  if (multi_rank(h) && part_xy && !tail) return fail(h, MIBA_ERR_INVALID, "x.y partials must follow y for the all-reduce");
+  return allreduce(h, y, 9 * (size_t)h->n_cam + (tail ? (size_t)h->red_nb : 0), ncclSum);
 }
 
 // constant parameter blocks: a zero scale removes the column from every kernel (F_s = F diag(sc))
@@ -680,22 +626,6 @@ int apply_const_mask(miba_handle h) {
   hipLaunchKernelGGL(k_mul, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_cfree, h->d_sc);
   HIPCHK(h, hipGetLastError());
   return MIBA_OK;
-}
-
-// Jacobi scale from the UNSCALED Jacobian currently in d_J
-int make_scale(miba_handle h) {
-  if (h->n_tiles)
-    hipLaunchKernelGGL(k_schur_matvec<1>, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
-                       h->d_pt_rng, h->d_tile_cams, h->d_slab_row, h->d_J, nullptr, nullptr, h->d_slab9, h->d_sp, nullptr);
-  hipLaunchKernelGGL(k_cam_reduce9, dim3(nblk(h->n_cam, 4)), dim3(256), 0, h->st, h->n_cam, h->d_cam_row_off, h->d_slab9,
-                     nullptr, nullptr, 0.0, h->d_sc, nullptr);
-  HIPCHK(h, hipGetLastError());
-  int rc = allreduce(h, h->d_sc, 9 * (size_t)h->n_cam, ncclSum);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_make_scale, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, 9 * (size_t)h->n_cam, h->d_sc, h->d_sc);
-  hipLaunchKernelGGL(k_make_scale, dim3(nblk(3 * (size_t)h->n_pt, 256)), dim3(256), 0, h->st, 3 * (size_t)h->n_pt, h->d_sp, h->d_sp);
-  HIPCHK(h, hipGetLastError());
-  return apply_const_mask(h);
 }
 
 int unit_scale(miba_handle h);
@@ -741,7 +671,7 @@ void launch_tail(miba_handle h, const TailArgs& A, bool reduce) {
   else hipLaunchKernelGGL((pcg_tail<MODE, false>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
 }
 
-int pcg_solve_mf(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
+int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
   const size_t n = 9 * (size_t)h->n_cam;
   const int nb = h->tail_nb;
   double* part_nb = h->d_part_pcg;
@@ -837,67 +767,6 @@ int pcg_solve_mf(miba_handle h, double q_tol, int min_it, int max_it, int check_
   return MIBA_OK;
 }
 
-// the same on the stored Jacobian (MIBA_MF=0): pcg_chkdir, product, pcg_dot, pcg_update per iteration
-int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
-  if (h->use_mf) return pcg_solve_mf(h, q_tol, min_it, max_it, check_every, n_it, status);
-  const size_t n = 9 * (size_t)h->n_cam;
-  const int nb = h->pcg_nb;
-  double* part_nb = h->d_part_pcg;
-  double* part_q = h->d_part_pcg + kPcgMaxBlocks;
-  double* part_rho[2] = {h->d_part_pcg + 2 * kPcgMaxBlocks, h->d_part_pcg + 3 * kPcgMaxBlocks};
-  classify_pcg_events(h, 1 << 30);   // pairs a solve that ended in an error has left behind are not kept waiting
-  const bool fused_pq = h->use_mf;   // the camera reduction of the matrix-free product leaves the p.q partials
-  double* part_pq = fused_pq ? h->d_pq + n : h->d_part_pcg + 4 * kPcgMaxBlocks;   // behind q: one all-reduce for both
-  const int n_pq = fused_pq ? h->red_nb : kPcgBlocks;
-  hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
-                     part_nb, part_rho[1]);
-  hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_nb, nb, h->d_ctl);
-  HIPCHK(h, hipGetLastError());
-  if (check_every < 1) check_every = 1;
-  for (int j = 1;; ++j) {
-    hipLaunchKernelGGL(pcg_chkdir, dim3(nb), dim3(256), 0, h->st, j, n, h->d_pz, h->d_pp, h->d_ctl, part_rho[(j - 1) & 1],
-                       part_rho[j & 1], nb, part_pq, n_pq, part_q, q_tol, min_it, max_it);
-    HIPCHK(h, hipGetLastError());
-    Ctl* cur = h->d_ctl + ((j - 1) & 1);   // C_{j-1}: state after the j-1 iterations tested so far
-    const int it = j - 1;
-    // Host poll: the control block is copied out and marked by an event, iteration j is enqueued behind it, and only
-    // then does the host wait for the copy: the device works on iteration j while the host looks at C_{j-1}, instead
-    // of idling for a host round trip (34 us per poll at Final-13682).  If C_{j-1} says done, iteration j's kernels
-    // return at once, like every launch enqueued past convergence.
-    const bool poll = it >= 1 && (it % check_every == 0 || it >= max_it);
-    if (poll) {
-      HIPCHK(h, hipMemcpyAsync(h->h_ctl, cur, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
-      HIPCHK(h, hipEventRecord(h->ev_poll, h->st));
-    }
-    int rc = schur_matvec(h, h->d_pp, h->d_pq, cur, part_pq, j);
-    if (rc) return rc;
-    if (!fused_pq) hipLaunchKernelGGL(pcg_dot, dim3(kPcgBlocks), dim3(256), 0, h->st, n, h->d_pp, h->d_pq, cur, part_pq);
-    const bool reset = (j % 10 == 0);  // residual_reset_period
-    if (!reset) {
-      hipLaunchKernelGGL(pcg_update<0>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
-                         h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
-    } else {
-      hipLaunchKernelGGL(pcg_update<1>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
-                         h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
-      HIPCHK(h, hipGetLastError());
-      rc = schur_matvec(h, h->d_px, h->d_pq, cur, nullptr, j);   // q = S p is dead once x is updated: reuse it for S x
-      if (rc) return rc;
-      hipLaunchKernelGGL(pcg_update<2>, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_pp, h->d_pq, h->d_rhs, h->d_Minv, h->d_px,
-                         h->d_pr, h->d_pz, cur, part_rho[j & 1], nb, part_pq, n_pq, part_q, part_rho[(j + 1) & 1]);
-    }
-    HIPCHK(h, hipGetLastError());
-    if (poll) {
-      HIPCHK(h, hipEventSynchronize(h->ev_poll));
-      if (h->h_ctl->done) break;
-      if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
-    }
-  }
-  *n_it = h->h_ctl->n_it;
-  *status = h->h_ctl->status;
-  classify_pcg_events(h, *n_it);
-  return MIBA_OK;
-}
-
 
 // ---- exact reduced solve (non-iterative linear_solver_type) ---------------------------------
 // Used when the options ask for a factorisation-based solver and the matrix-free kernels are active:
@@ -909,7 +778,7 @@ enum { kExactNone = 0, kExactDense = 1, kExactSparse = 2 };
 int sparse_symbolic(miba_handle h);
 int exact_kind(miba_handle h, const miba_options* o, int* kind) {
   *kind = kExactNone;
-  if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR || !h->use_mf) return MIBA_OK;
+  if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR) return MIBA_OK;
   const char* e = getenv("MIBA_DENSE");
   if (e && atoi(e) == 0) return MIBA_OK;
   const char* x = getenv("MIBA_EXACT");
@@ -1322,7 +1191,7 @@ int linear_solve(miba_handle h, const miba_options* o, int* n_it, int* status) {
 // back-substitution, candidate state, model cost change, step / candidate norms
 // reduce = false: the caller all-reduces S_MCC, S_DP2, S_XP2 itself (together with the candidate cost)
 int backsub_and_candidate(miba_handle h, bool reduce = true) {
-  if (h->use_mf) {
+  {
     if (h->n_tiles) {
       Timed t(h, MIBA_K_BACKSUB);
 #define MIBA_BACKSUB_ARGS(n_blocks, list)                                                                                 \
@@ -1337,11 +1206,6 @@ int backsub_and_candidate(miba_handle h, bool reduce = true) {
       }
 #undef MIBA_BACKSUB_ARGS
     }
-  } else if (h->n_tiles) {
-    Timed t(h, MIBA_K_BACKSUB);
-    hipLaunchKernelGGL(k_backsub, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_grps, h->d_idx,
-                       h->d_pt_rng, h->d_tile_cams, h->d_J, h->d_Cinv, h->d_gp, h->d_px, h->d_sp, h->d_X, h->d_yp, h->d_Xc,
-                       h->d_part_tile);
   }
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 0, 0, h->d_sum + S_MCC);
@@ -1390,41 +1254,19 @@ int read_scalars(miba_handle h) {
   return MIBA_OK;
 }
 
-// make d_J the scaled Jacobian of the current state (computing the Jacobi scale on first use)
+// camera tables of the current state and, on first use, the Jacobi scale: nothing is stored per observation
 int ensure_jacobian(miba_handle h, const miba_options* o) {
   int rc;
-  if (h->use_mf) {
-    // matrix-free: nothing is stored per observation; only the camera tables and (once) the Jacobi scale
-    if (!h->jac_valid || !h->scale_valid) {
-      rc = launch_cam_tables(h, h->d_cam);
-      if (rc) return rc;
-    }
-    if (!h->scale_valid) {
-      rc = o->jacobi_scaling ? make_scale_mf(h, o) : unit_scale_masked(h);
-      if (rc) return rc;
-      h->scale_valid = true;
-    }
-    h->jac_valid = true;
-    return MIBA_OK;
+  if (!h->jac_valid || !h->scale_valid) {
+    rc = launch_cam_tables(h, h->d_cam);
+    if (rc) return rc;
   }
   if (!h->scale_valid) {
-    if (o->jacobi_scaling) {
-      rc = eval_jac(h, h->d_cam, h->d_X, false);
-      if (rc) return rc;
-      rc = make_scale(h);
-      if (rc) return rc;
-    } else {
-      rc = unit_scale_masked(h);
-      if (rc) return rc;
-    }
-    h->scale_valid = true;
-    h->jac_valid = false;
-  }
-  if (!h->jac_valid) {
-    rc = eval_jac(h, h->d_cam, h->d_X, true);
+    rc = o->jacobi_scaling ? make_scale_mf(h, o) : unit_scale_masked(h);
     if (rc) return rc;
-    h->jac_valid = true;
+    h->scale_valid = true;
   }
+  h->jac_valid = true;
   return MIBA_OK;
 }
 
@@ -1513,12 +1355,6 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
   if (const char* te = getenv("MIBA_TIME_EVERY")) { const int v = atoi(te); if (v >= 1) h->time_every = v; }
   if (e != hipSuccess) {
     int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
-    delete h;
-    return rc;
-  }
-  e = hipFuncSetAttribute((const void*)k_schur_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK2Lds);
-  if (e != hipSuccess) {
-    int rc = fail(nullptr, MIBA_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     delete h;
     return rc;
   }
@@ -1787,14 +1623,6 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   }
   auto obs_x = [&](int64_t o) { return h->cam_model ? h->principal[2 * (size_t)p->obs_cam[o]] - p->obs_xy[2 * o] : p->obs_xy[2 * o]; };
   auto obs_y = [&](int64_t o) { return h->cam_model ? h->principal[2 * (size_t)p->obs_cam[o] + 1] - p->obs_xy[2 * o + 1] : p->obs_xy[2 * o + 1]; };
-  {
-    const char* mf = getenv("MIBA_MF");   // matrix-free kernels are the default; MIBA_MF=0 selects the stored-Jacobian path
-    h->use_mf = !(mf && mf[0] == '0');
-    const char* op = getenv("MIBA_K2_ONEPASS");
-    h->k2_onepass = op && op[0] == '1';
-  }
-  if (h->cam_model == MIBA_MODEL_REFERENCE && (!h->use_mf || h->k2_onepass))
-    return fail(h, MIBA_ERR_INVALID, "camera model 1 needs the two-pass matrix-free kernels (MIBA_MF=0 or MIBA_K2_ONEPASS=1 is set)");
   const char* po = getenv("MIBA_POINT_ORDER");
   // the ranks of a single-process group share one plan (built once by the group), a stand-alone rank builds its own
   if (shared) h->plan_sp = shared; else h->plan_sp = std::make_shared<Plan>();
@@ -1976,9 +1804,9 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false; h->dense_plan_tried = false; h->d_camacc2 = nullptr;
   h->sparse_state = 0; h->d_sp_tiles = nullptr;
   h->d_omega = nullptr;
-  ALLOC(h->d_Cinv, 6 * np); ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
+  ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
   // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
-  ALLOC(h->d_slab64, (!h->use_mf || h->k2_onepass) ? (size_t)kK2W * n_rows : (size_t)1); ALLOC(h->d_slab9, 9 * (size_t)n_rows);
+  ALLOC(h->d_slab9, 9 * (size_t)n_rows);
   ALLOC(h->d_camacc, (size_t)kK2W * nc); ALLOC(h->d_Minv, 81 * nc); ALLOC(h->d_Dc2, 9 * nc); ALLOC(h->d_rhs, 9 * nc);
   ALLOC(h->d_px, 9 * nc); ALLOC(h->d_pr, 9 * nc); ALLOC(h->d_pz, 9 * nc); ALLOC(h->d_pp, 9 * nc); ALLOC(h->d_pq, 9 * nc + kPcgMaxBlocks);
   ALLOC(h->d_probe, 9 * nc);
@@ -2270,7 +2098,7 @@ int miba_evaluate(miba_handle h, double* cost, double* residuals, double* jac_ca
   miba_options o;
   miba_default_options(&o);
   int rc;
-  if (residuals || jac_cam || jac_pt || !h->use_mf) {
+  if (residuals || jac_cam || jac_pt) {
     rc = eval_jac(h, h->d_cam, h->d_X, false);
     h->jac_valid = false;  // d_J now holds the unscaled Jacobian
   } else {
@@ -2404,7 +2232,6 @@ int miba_get_reduced_system(miba_handle h, double* S_out) {
   if (!h || !h->has_problem || !S_out) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->jac_valid) return fail(h, MIBA_ERR_INVALID, "call miba_linear_step first (Schur blocks not set up)");
-  if (!h->use_mf) return fail(h, MIBA_ERR_INVALID, "the explicit reduced system needs the matrix-free kernels (MIBA_MF=0 is set)");
   const size_t n = 9 * (size_t)h->n_cam;
   if ((n + kNB - 1) / kNB * kNB > (size_t)kDenseMaxN) return fail(h, MIBA_ERR_INVALID, "too many cameras for the dense reduced system (%d > %d rows)", (int)n, kDenseMaxN);
   int rc = dense_assemble(h);

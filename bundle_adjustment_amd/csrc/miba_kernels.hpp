@@ -338,524 +338,12 @@ __device__ __forceinline__ bool spd3_inverse(const double* a, double* ci /*c00,c
   return true;
 }
 
-__device__ __forceinline__ void load_FE(const double* __restrict__ Jc, double* F, double* E) {
-#pragma unroll
-  for (int k = 0; k < 18; ++k) F[k] = Jc[(size_t)k * kChunk];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) E[k] = Jc[(size_t)(18 + k) * kChunk];
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2: Schur init.  Per point: C = E'E + Dp^2 -> C^-1, g = E'r, diag(E'E); per camera slab row
-// (64 doubles): upper triangle of F'F (45), F'(r - E C^-1 g) (9), F'r (9).
-// inv_radius: D^2 = clamp(diag, dmin, dmax) * inv_radius.
-// ---------------------------------------------------------------------------------------------
-constexpr int kK2W = 64;
-__global__ __launch_bounds__(256) void k_schur_init(const Tile* __restrict__ tiles, const Group* __restrict__ grps,
-                                                    const int32_t* __restrict__ idx, const int2* __restrict__ pt_rng,
-                                                    const int32_t* __restrict__ slab_row, const double* __restrict__ J,
-                                                    double inv_radius, double dmin, double dmax,
-                                                    double* __restrict__ Cinv /*[npt][6]*/, double* __restrict__ gp /*[npt][3]*/,
-                                                    double* __restrict__ dgp /*[npt][3] diag E'E*/,
-                                                    double* __restrict__ slab /*[nrows][64]*/, Ctl* __restrict__ ctl,
-                                                    const double* __restrict__ X, const double* __restrict__ sp,
-                                                    double* __restrict__ ptrec /*[npt][kPtRec]: X, sp C^-1 g, sp C^-1 sp*/) {
-  extern __shared__ double lds[];
-  double* s_acc = lds;                              // [kMaxCamSlots][63]  (stride 63: odd => fewer bank conflicts)
-  double* s_stage = lds + kMaxCamSlots * 63;        // [256][9]
-  double* s_y = s_stage + kChunk * 9;               // [256][3]
-  double* s4 = s_y + kChunk * 3;                    // [4]
-  const Tile t = tiles[blockIdx.x];
-  const int tid = threadIdx.x;
-  if (!t.giant)
-    for (int i = tid; i < t.ncs * 63; i += kChunk) s_acc[i] = 0.0;
-  __syncthreads();
-  for (int g = 0; g < t.ngrp; ++g) {
-    const Group G = grps[t.grp0 + g];
-    if (G.nchunk == 1) {
-      const size_t chunk = (size_t)G.chunk0;
-      const size_t slot = chunk * kChunk + tid;
-      const int32_t w = idx[slot];
-      const bool valid = w >= 0;
-      const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-      double F[18], E[6], r0 = 0.0, r1 = 0.0;
-      if (valid) {
-        load_FE(Jc, F, E);
-        r0 = Jc[(size_t)24 * kChunk]; r1 = Jc[(size_t)25 * kChunk];
-        double* st = s_stage + tid * 9;
-        st[0] = E[0] * E[0] + E[3] * E[3];
-        st[1] = E[1] * E[0] + E[4] * E[3];
-        st[2] = E[1] * E[1] + E[4] * E[4];
-        st[3] = E[2] * E[0] + E[5] * E[3];
-        st[4] = E[2] * E[1] + E[5] * E[4];
-        st[5] = E[2] * E[2] + E[5] * E[5];
-        st[6] = E[0] * r0 + E[3] * r1;
-        st[7] = E[1] * r0 + E[4] * r1;
-        st[8] = E[2] * r0 + E[5] * r1;
-      }
-      __syncthreads();
-      if (tid < G.npt) {
-        const int p = G.pt0 + tid;
-        const int2 rg = pt_rng[p];
-        const int l0 = rg.x - (int)(chunk * kChunk);
-        double a[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) a[k] = 0.0;
-        for (int l = l0; l < l0 + rg.y; ++l) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) a[k] += s_stage[l * 9 + k];
-        }
-        dgp[3 * (size_t)p] = a[0]; dgp[3 * (size_t)p + 1] = a[2]; dgp[3 * (size_t)p + 2] = a[5];
-        double c[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
-        c[0] += fmin(fmax(a[0], dmin), dmax) * inv_radius;
-        c[2] += fmin(fmax(a[2], dmin), dmax) * inv_radius;
-        c[5] += fmin(fmax(a[5], dmin), dmax) * inv_radius;
-        double ci[6];
-        if (!spd3_inverse(c, ci)) {
-          ctl->fail = 1;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) ci[k] = 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Cinv[6 * (size_t)p + k] = ci[k];
-        {
-          // per-point record of the matrix-free product: X, diag(sp) C^-1 diag(sp), slot range in the chunk
-          double* rp = ptrec + (size_t)kPtRec * (size_t)p;
-          const double s0 = sp[3 * (size_t)p], s1 = sp[3 * (size_t)p + 1], s2 = sp[3 * (size_t)p + 2];
-          rp[0] = X[3 * (size_t)p]; rp[1] = X[3 * (size_t)p + 1]; rp[2] = X[3 * (size_t)p + 2];
-          rp[6] = s0 * ci[0] * s0; rp[7] = s1 * ci[1] * s0; rp[8] = s1 * ci[2] * s1;
-          rp[9] = s2 * ci[3] * s0; rp[10] = s2 * ci[4] * s1; rp[11] = s2 * ci[5] * s2;
-        }
-        gp[3 * (size_t)p] = a[6]; gp[3 * (size_t)p + 1] = a[7]; gp[3 * (size_t)p + 2] = a[8];
-        s_y[tid * 3 + 0] = ci[0] * a[6] + ci[1] * a[7] + ci[3] * a[8];
-        s_y[tid * 3 + 1] = ci[1] * a[6] + ci[2] * a[7] + ci[4] * a[8];
-        s_y[tid * 3 + 2] = ci[3] * a[6] + ci[4] * a[7] + ci[5] * a[8];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ptrec[(size_t)kPtRec * (size_t)p + 3 + k] = sp[3 * (size_t)p + k] * s_y[tid * 3 + k];
-      }
-      __syncthreads();
-      if (valid) {
-        const int pl = w & 0xFF;
-        const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
-        const double v0 = r0 - (E[0] * y0 + E[1] * y1 + E[2] * y2);
-        const double v1 = r1 - (E[3] * y0 + E[4] * y1 + E[5] * y2);
-        double* dst;
-        if (t.giant) dst = slab + (size_t)kK2W * slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
-        else dst = s_acc + 63 * ((w >> 8) & 0xFF);
-        int o = 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i)
-#pragma unroll
-          for (int j = i; j < 9; ++j) {
-            const double v = F[i] * F[j] + F[9 + i] * F[9 + j];
-            if (t.giant) dst[o] = v; else atomicAdd(dst + o, v);
-            ++o;
-          }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const double v = F[k] * v0 + F[9 + k] * v1;
-          const double u = F[k] * r0 + F[9 + k] * r1;
-          if (t.giant) { dst[45 + k] = v; dst[54 + k] = u; }
-          else { atomicAdd(dst + 45 + k, v); atomicAdd(dst + 54 + k, u); }
-        }
-        if (t.giant) dst[63] = 0.0;
-      }
-    } else {
-      // giant point spanning several chunks: block-wide sums, two passes over its chunks
-      const int p = G.pt0;
-      double a[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) a[k] = 0.0;
-      for (int ch = 0; ch < G.nchunk; ++ch) {
-        const size_t chunk = (size_t)(G.chunk0 + ch);
-        const size_t slot = chunk * kChunk + tid;
-        const bool valid = idx[slot] >= 0;
-        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-        double v[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = 0.0;
-        if (valid) {
-          double E[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) E[k] = Jc[(size_t)(18 + k) * kChunk];
-          const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
-          v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[1] * E[0] + E[4] * E[3]; v[2] = E[1] * E[1] + E[4] * E[4];
-          v[3] = E[2] * E[0] + E[5] * E[3]; v[4] = E[2] * E[1] + E[5] * E[4]; v[5] = E[2] * E[2] + E[5] * E[5];
-          v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) a[k] += block_sum(v[k], s4);
-      }
-      double c[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
-      c[0] += fmin(fmax(a[0], dmin), dmax) * inv_radius;
-      c[2] += fmin(fmax(a[2], dmin), dmax) * inv_radius;
-      c[5] += fmin(fmax(a[5], dmin), dmax) * inv_radius;
-      double ci[6];
-      if (!spd3_inverse(c, ci)) {
-        if (tid == 0) ctl->fail = 1;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ci[k] = 0.0;
-      }
-      if (tid == 0) {
-        dgp[3 * (size_t)p] = a[0]; dgp[3 * (size_t)p + 1] = a[2]; dgp[3 * (size_t)p + 2] = a[5];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Cinv[6 * (size_t)p + k] = ci[k];
-        gp[3 * (size_t)p] = a[6]; gp[3 * (size_t)p + 1] = a[7]; gp[3 * (size_t)p + 2] = a[8];
-      }
-      const double y0 = ci[0] * a[6] + ci[1] * a[7] + ci[3] * a[8];
-      const double y1 = ci[1] * a[6] + ci[2] * a[7] + ci[4] * a[8];
-      const double y2 = ci[3] * a[6] + ci[4] * a[7] + ci[5] * a[8];
-      for (int ch = 0; ch < G.nchunk; ++ch) {
-        const size_t chunk = (size_t)(G.chunk0 + ch);
-        const size_t slot = chunk * kChunk + tid;
-        if (idx[slot] < 0) continue;
-        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-        double F[18], E[6];
-        load_FE(Jc, F, E);
-        const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
-        const double v0 = r0 - (E[0] * y0 + E[1] * y1 + E[2] * y2);
-        const double v1 = r1 - (E[3] * y0 + E[4] * y1 + E[5] * y2);
-        double* dst = slab + (size_t)kK2W * slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
-        int o = 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i)
-#pragma unroll
-          for (int j = i; j < 9; ++j) dst[o++] = F[i] * F[j] + F[9 + i] * F[9 + j];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          dst[45 + k] = F[k] * v0 + F[9 + k] * v1;
-          dst[54 + k] = F[k] * r0 + F[9 + k] * r1;
-        }
-        dst[63] = 0.0;
-      }
-    }
-  }
-  __syncthreads();
-  if (!t.giant) {
-    for (int i = tid; i < t.ncs * kK2W; i += kChunk) {
-      const int s = i >> 6, k = i & 63;
-      slab[(size_t)kK2W * slab_row[t.cam0 + s] + k] = (k < 63) ? s_acc[s * 63 + k] : 0.0;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3: y = S x without the D^2 x term (added by k_cam_reduce9):  per tile
-//   u = F x_c ; y2_p = sum E'u ; y3 = -C^-1 y2 ; w = u + E y3 ; slab row = sum F'w
-// MODE 0: matvec (above).  MODE 1: squared column norms (Jacobi scaling at iteration 0):
-//   slab row = sum F.^2, nrm_p = sum E.^2.
-// ---------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void k_schur_matvec(const Tile* __restrict__ tiles, const Group* __restrict__ grps,
-                                                      const int32_t* __restrict__ idx, const int2* __restrict__ pt_rng,
-                                                      const int32_t* __restrict__ tile_cams,
-                                                      const int32_t* __restrict__ slab_row, const double* __restrict__ J,
-                                                      const double* __restrict__ Cinv, const double* __restrict__ x,
-                                                      double* __restrict__ slab /*[nrows][9]*/,
-                                                      double* __restrict__ nrm_p /*[npt][3], MODE 1*/,
-                                                      const Ctl* __restrict__ ctl) {
-  __shared__ double s_x[kMaxCamSlots * 9];
-  __shared__ double s_acc[kMaxCamSlots * 9];
-  __shared__ double s_stage[kChunk * 3];
-  __shared__ double s_y[kChunk * 3];
-  __shared__ double s4[4];
-  if (MODE == 0 && ctl->done) return;
-  const Tile t = tiles[blockIdx.x];
-  const int tid = threadIdx.x;
-  if (!t.giant) {
-    for (int i = tid; i < t.ncs * 9; i += kChunk) {
-      if (MODE == 0) s_x[i] = x[9 * (size_t)tile_cams[t.cam0 + i / 9] + i % 9];
-      s_acc[i] = 0.0;
-    }
-  }
-  __syncthreads();
-  for (int g = 0; g < t.ngrp; ++g) {
-    const Group G = grps[t.grp0 + g];
-    if (G.nchunk == 1) {
-      const size_t chunk = (size_t)G.chunk0;
-      const size_t slot = chunk * kChunk + tid;
-      const int32_t w = idx[slot];
-      const bool valid = w >= 0;
-      const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-      double F[18], E[6], u0 = 0.0, u1 = 0.0;
-      const int cs = (w >> 8) & 0xFF;
-      if (valid) {
-        load_FE(Jc, F, E);
-        if (MODE == 0) {
-          const double* xc = t.giant ? (x + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)]) : (s_x + 9 * cs);
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { const double xv = xc[k]; u0 += F[k] * xv; u1 += F[9 + k] * xv; }
-          s_stage[tid * 3 + 0] = E[0] * u0 + E[3] * u1;
-          s_stage[tid * 3 + 1] = E[1] * u0 + E[4] * u1;
-          s_stage[tid * 3 + 2] = E[2] * u0 + E[5] * u1;
-        } else {
-          s_stage[tid * 3 + 0] = E[0] * E[0] + E[3] * E[3];
-          s_stage[tid * 3 + 1] = E[1] * E[1] + E[4] * E[4];
-          s_stage[tid * 3 + 2] = E[2] * E[2] + E[5] * E[5];
-        }
-      }
-      __syncthreads();
-      if (tid < G.npt) {
-        const int p = G.pt0 + tid;
-        const int2 rg = pt_rng[p];
-        const int l0 = rg.x - (int)(chunk * kChunk);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int l = l0; l < l0 + rg.y; ++l) { a0 += s_stage[l * 3]; a1 += s_stage[l * 3 + 1]; a2 += s_stage[l * 3 + 2]; }
-        if (MODE == 0) {
-          const double* ci = Cinv + 6 * (size_t)p;
-          s_y[tid * 3 + 0] = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2);
-          s_y[tid * 3 + 1] = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2);
-          s_y[tid * 3 + 2] = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2);
-        } else {
-          nrm_p[3 * (size_t)p] = a0; nrm_p[3 * (size_t)p + 1] = a1; nrm_p[3 * (size_t)p + 2] = a2;
-        }
-      }
-      if (MODE == 0) __syncthreads();
-      if (valid) {
-        double w0 = 0.0, w1 = 0.0;
-        if (MODE == 0) {
-          const int pl = w & 0xFF;
-          const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
-          w0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
-          w1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
-        }
-        if (t.giant) {
-          double* dst = slab + 9 * (size_t)slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) dst[k] = (MODE == 0) ? F[k] * w0 + F[9 + k] * w1 : F[k] * F[k] + F[9 + k] * F[9 + k];
-        } else {
-          double* dst = s_acc + 9 * cs;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) atomicAdd(dst + k, (MODE == 0) ? F[k] * w0 + F[9 + k] * w1 : F[k] * F[k] + F[9 + k] * F[9 + k]);
-        }
-      }
-      __syncthreads();  // s_stage / s_y are reused by the next group
-    } else {
-      const int p = G.pt0;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      for (int ch = 0; ch < G.nchunk; ++ch) {
-        const size_t chunk = (size_t)(G.chunk0 + ch);
-        const size_t slot = chunk * kChunk + tid;
-        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-        if (idx[slot] >= 0) {
-          double F[18], E[6];
-          load_FE(Jc, F, E);
-          if (MODE == 0) {
-            const double* xc = x + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)];
-            double u0 = 0.0, u1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
-            v0 = E[0] * u0 + E[3] * u1; v1 = E[1] * u0 + E[4] * u1; v2 = E[2] * u0 + E[5] * u1;
-          } else {
-            v0 = E[0] * E[0] + E[3] * E[3]; v1 = E[1] * E[1] + E[4] * E[4]; v2 = E[2] * E[2] + E[5] * E[5];
-          }
-        }
-        a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
-      }
-      double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-      if (MODE == 0) {
-        const double* ci = Cinv + 6 * (size_t)p;
-        y0 = -(ci[0] * a0 + ci[1] * a1 + ci[3] * a2);
-        y1 = -(ci[1] * a0 + ci[2] * a1 + ci[4] * a2);
-        y2 = -(ci[3] * a0 + ci[4] * a1 + ci[5] * a2);
-      } else if (tid == 0) {
-        nrm_p[3 * (size_t)p] = a0; nrm_p[3 * (size_t)p + 1] = a1; nrm_p[3 * (size_t)p + 2] = a2;
-      }
-      for (int ch = 0; ch < G.nchunk; ++ch) {
-        const size_t chunk = (size_t)(G.chunk0 + ch);
-        const size_t slot = chunk * kChunk + tid;
-        if (idx[slot] < 0) continue;
-        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-        double F[18], E[6];
-        load_FE(Jc, F, E);
-        const int pos = (int)(slot - (size_t)t.slot0);
-        double* dst = slab + 9 * (size_t)slab_row[t.cam0 + pos];
-        if (MODE == 0) {
-          const double* xc = x + 9 * (size_t)tile_cams[t.cam0 + pos];
-          double u0 = 0.0, u1 = 0.0;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
-          const double w0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
-          const double w1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) dst[k] = F[k] * w0 + F[9 + k] * w1;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) dst[k] = F[k] * F[k] + F[9 + k] * F[9 + k];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (!t.giant)
-    for (int i = tid; i < t.ncs * 9; i += kChunk) slab[9 * (size_t)slab_row[t.cam0 + i / 9] + i % 9] = s_acc[i];
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4: back-substitution  y_p = C^-1 (g_p - sum E'F y_c), model cost change, candidate points.
-//   partial[4*tile + {0,1,2}] = {sum Jy.(r - Jy/2), |delta_p|^2, |x_cand_p|^2}
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_backsub(const Tile* __restrict__ tiles, const Group* __restrict__ grps,
-                                                 const int32_t* __restrict__ idx, const int2* __restrict__ pt_rng,
-                                                 const int32_t* __restrict__ tile_cams, const double* __restrict__ J,
-                                                 const double* __restrict__ Cinv, const double* __restrict__ gp,
-                                                 const double* __restrict__ yc /*[ncam][9]*/,
-                                                 const double* __restrict__ sp /*[npt][3]*/, const double* __restrict__ X,
-                                                 double* __restrict__ yp /*[npt][3]*/, double* __restrict__ Xc,
-                                                 double* __restrict__ partial) {
-  __shared__ double s_x[kMaxCamSlots * 9];
-  __shared__ double s_stage[kChunk * 3];
-  __shared__ double s_y[kChunk * 3];
-  __shared__ double s4[4];
-  const Tile t = tiles[blockIdx.x];
-  const int tid = threadIdx.x;
-  if (!t.giant)
-    for (int i = tid; i < t.ncs * 9; i += kChunk) s_x[i] = yc[9 * (size_t)tile_cams[t.cam0 + i / 9] + i % 9];
-  __syncthreads();
-  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0;
-  for (int g = 0; g < t.ngrp; ++g) {
-    const Group G = grps[t.grp0 + g];
-    if (G.nchunk == 1) {
-      const size_t chunk = (size_t)G.chunk0;
-      const size_t slot = chunk * kChunk + tid;
-      const int32_t w = idx[slot];
-      const bool valid = w >= 0;
-      const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-      double E[6], u0 = 0.0, u1 = 0.0;
-      if (valid) {
-        double F[18];
-        load_FE(Jc, F, E);
-        const double* xc = t.giant ? (yc + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)]) : (s_x + 9 * ((w >> 8) & 0xFF));
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { const double xv = xc[k]; u0 += F[k] * xv; u1 += F[9 + k] * xv; }
-        s_stage[tid * 3 + 0] = E[0] * u0 + E[3] * u1;
-        s_stage[tid * 3 + 1] = E[1] * u0 + E[4] * u1;
-        s_stage[tid * 3 + 2] = E[2] * u0 + E[5] * u1;
-      }
-      __syncthreads();
-      if (tid < G.npt) {
-        const int p = G.pt0 + tid;
-        const int2 rg = pt_rng[p];
-        const int l0 = rg.x - (int)(chunk * kChunk);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int l = l0; l < l0 + rg.y; ++l) { a0 += s_stage[l * 3]; a1 += s_stage[l * 3 + 1]; a2 += s_stage[l * 3 + 2]; }
-        const double* ci = Cinv + 6 * (size_t)p;
-        const double b0 = gp[3 * (size_t)p] - a0, b1 = gp[3 * (size_t)p + 1] - a1, b2 = gp[3 * (size_t)p + 2] - a2;
-        const double y0 = ci[0] * b0 + ci[1] * b1 + ci[3] * b2;
-        const double y1 = ci[1] * b0 + ci[2] * b1 + ci[4] * b2;
-        const double y2 = ci[3] * b0 + ci[4] * b1 + ci[5] * b2;
-        s_y[tid * 3] = y0; s_y[tid * 3 + 1] = y1; s_y[tid * 3 + 2] = y2;
-        yp[3 * (size_t)p] = y0; yp[3 * (size_t)p + 1] = y1; yp[3 * (size_t)p + 2] = y2;
-        const double d0 = -y0 * sp[3 * (size_t)p], d1 = -y1 * sp[3 * (size_t)p + 1], d2 = -y2 * sp[3 * (size_t)p + 2];
-        const double c0 = X[3 * (size_t)p] + d0, c1 = X[3 * (size_t)p + 1] + d1, c2 = X[3 * (size_t)p + 2] + d2;
-        Xc[3 * (size_t)p] = c0; Xc[3 * (size_t)p + 1] = c1; Xc[3 * (size_t)p + 2] = c2;
-        // step norm exactly as Ceres: |x - x_cand|
-        const double e0 = X[3 * (size_t)p] - c0, e1 = X[3 * (size_t)p + 1] - c1, e2 = X[3 * (size_t)p + 2] - c2;
-        dp2 += e0 * e0 + e1 * e1 + e2 * e2;
-        xp2 += c0 * c0 + c1 * c1 + c2 * c2;
-      }
-      __syncthreads();
-      if (valid) {
-        const int pl = w & 0xFF;
-        const double y0 = s_y[pl * 3], y1 = s_y[pl * 3 + 1], y2 = s_y[pl * 3 + 2];
-        const double m0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
-        const double m1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
-        const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
-        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
-      }
-      __syncthreads();
-    } else {
-      const int p = G.pt0;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      for (int ch = 0; ch < G.nchunk; ++ch) {
-        const size_t chunk = (size_t)(G.chunk0 + ch);
-        const size_t slot = chunk * kChunk + tid;
-        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-        if (idx[slot] >= 0) {
-          double F[18], E[6];
-          load_FE(Jc, F, E);
-          const double* xc = yc + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)];
-          double u0 = 0.0, u1 = 0.0;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
-          v0 = E[0] * u0 + E[3] * u1; v1 = E[1] * u0 + E[4] * u1; v2 = E[2] * u0 + E[5] * u1;
-        }
-        a0 += block_sum(v0, s4); a1 += block_sum(v1, s4); a2 += block_sum(v2, s4);
-      }
-      const double* ci = Cinv + 6 * (size_t)p;
-      const double b0 = gp[3 * (size_t)p] - a0, b1 = gp[3 * (size_t)p + 1] - a1, b2 = gp[3 * (size_t)p + 2] - a2;
-      const double y0 = ci[0] * b0 + ci[1] * b1 + ci[3] * b2;
-      const double y1 = ci[1] * b0 + ci[2] * b1 + ci[4] * b2;
-      const double y2 = ci[3] * b0 + ci[4] * b1 + ci[5] * b2;
-      if (tid == 0) {
-        yp[3 * (size_t)p] = y0; yp[3 * (size_t)p + 1] = y1; yp[3 * (size_t)p + 2] = y2;
-        const double c0 = X[3 * (size_t)p] - y0 * sp[3 * (size_t)p], c1 = X[3 * (size_t)p + 1] - y1 * sp[3 * (size_t)p + 1],
-                     c2 = X[3 * (size_t)p + 2] - y2 * sp[3 * (size_t)p + 2];
-        Xc[3 * (size_t)p] = c0; Xc[3 * (size_t)p + 1] = c1; Xc[3 * (size_t)p + 2] = c2;
-        const double e0 = X[3 * (size_t)p] - c0, e1 = X[3 * (size_t)p + 1] - c1, e2 = X[3 * (size_t)p + 2] - c2;
-        dp2 += e0 * e0 + e1 * e1 + e2 * e2;
-        xp2 += c0 * c0 + c1 * c1 + c2 * c2;
-      }
-      for (int ch = 0; ch < G.nchunk; ++ch) {
-        const size_t chunk = (size_t)(G.chunk0 + ch);
-        const size_t slot = chunk * kChunk + tid;
-        if (idx[slot] < 0) continue;
-        const double* Jc = J + chunk * (size_t)(kJComp * kChunk) + tid;
-        double F[18], E[6];
-        load_FE(Jc, F, E);
-        const double* xc = yc + 9 * (size_t)tile_cams[t.cam0 + (int)(slot - (size_t)t.slot0)];
-        double u0 = 0.0, u1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { u0 += F[k] * xc[k]; u1 += F[9 + k] * xc[k]; }
-        const double m0 = u0 + E[0] * y0 + E[1] * y1 + E[2] * y2;
-        const double m1 = u1 + E[3] * y0 + E[4] * y1 + E[5] * y2;
-        const double r0 = Jc[(size_t)24 * kChunk], r1 = Jc[(size_t)25 * kChunk];
-        mcc += m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
-      }
-    }
-  }
-  const double s0 = block_sum(mcc, s4);
-  const double s1 = block_sum(dp2, s4);
-  const double s2 = block_sum(xp2, s4);
-  if (tid == 0) {
-    partial[4 * (size_t)blockIdx.x + 0] = s0;
-    partial[4 * (size_t)blockIdx.x + 1] = s1;
-    partial[4 * (size_t)blockIdx.x + 2] = s2;
-    partial[4 * (size_t)blockIdx.x + 3] = 0.0;
-  }
-}
+constexpr int kK2W = 64;   // width of a camera row of the Schur init: upper triangle of F'F (45), F'(r - E z) (9), F'r (9), one spare
 
 // ---------------------------------------------------------------------------------------------
 // Camera-major slab reductions (deterministic: rows are summed in row order per camera).
 // One wave per camera.  cam_row_off[c]..cam_row_off[c+1] = rows of camera c on this shard.
 // ---------------------------------------------------------------------------------------------
-// W = 9:  out[c][k] = diag_w * d2[c][k] * x[c][k] + sum rows      (d2 may be null)
-__global__ __launch_bounds__(256) void k_cam_reduce9(int n_cam, const int32_t* __restrict__ cam_row_off,
-                                                     const double* __restrict__ slab, const double* __restrict__ d2,
-                                                     const double* __restrict__ x, double diag_w,
-                                                     double* __restrict__ out, const Ctl* __restrict__ ctl) {
-  if (ctl && ctl->done) return;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= n_cam) return;
-  const int lane = threadIdx.x & 63;
-  const int r0 = cam_row_off[c], r1 = cam_row_off[c + 1];
-  const int sub = lane / 9, k = lane % 9;  // 7 row lanes x 9 components (lane 63 idle)
-  double acc = 0.0;
-  if (lane < 63)
-    for (int r = r0 + sub; r < r1; r += 7) acc += slab[9 * (size_t)r + k];
-  // combine the 7 sub-rows in fixed order: lanes k, k+9, ..., k+54
-  double tot = acc;
-#pragma unroll
-  for (int s = 1; s < 7; ++s) tot += __shfl(acc, k + 9 * s, 64);
-  if (lane < 9) {
-    double v = tot;
-    if (d2) v += diag_w * d2[9 * (size_t)c + k] * x[9 * (size_t)c + k];
-    out[9 * (size_t)c + k] = v;
-  }
-}
-
 // W = 64: out[c][0..63] = sum rows (lane = component)
 // sc != null: the rows hold sums of the UNSCALED Jacobian (K2-mf); entry (i,j) of F'F is scaled by
 // sc_i sc_j, F'v and F'r by sc_i.
@@ -976,21 +464,6 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const do
   if (threadIdx.x == 0) { partial[2 * (size_t)blockIdx.x] = m; partial[2 * (size_t)blockIdx.x + 1] = s; }
 }
 
-// point gradient norms (unscaled): g_p / sp
-__global__ __launch_bounds__(256) void k_pt_gradnorm(int n_pt, const double* __restrict__ gp, const double* __restrict__ sp,
-                                                     double* __restrict__ partial /*[nblk][2]*/) {
-  __shared__ double s4[4];
-  double gmax = 0.0, g2 = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * (size_t)n_pt; i += (size_t)gridDim.x * blockDim.x) {
-    const double g = gp[i] / sp[i];
-    gmax = fmax(gmax, fabs(g));
-    g2 += g * g;
-  }
-  const double m = block_max(gmax, s4);
-  const double s = block_sum(g2, s4);
-  if (threadIdx.x == 0) { partial[2 * (size_t)blockIdx.x] = m; partial[2 * (size_t)blockIdx.x + 1] = s; }
-}
-
 // out[slot] = sum (or max) over n entries of partial[i*stride + off]; single 1024-thread block.
 __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ partial, size_t n, int stride, int off,
                                                  int is_max, double* __restrict__ out) {
@@ -1078,9 +551,10 @@ __device__ __forceinline__ bool pcg_bad(double v) { return v == 0.0 || isinf(v) 
 // The control block is double-buffered: C_k (state after k completed iterations) lives in ctl[k & 1], so a
 // kernel that produces C_k never writes the buffer its sibling blocks are still reading (C_{k-1}).
 //
-// One PCG iteration j (1-based) is   pcg_chkdir(j) -> mat-vec (+ pq partials) -> pcg_update(j):
-//   pcg_chkdir(j): end-of-iteration test of j-1 (C_{j-2} -> C_{j-1}), then rho_j, beta, p = z + beta p
-//   pcg_update(j): alpha = rho_j / pq; x += alpha p; r -= alpha q; Q partials; z = M^-1 r; rho_{j+1} partials
+// One PCG iteration j (1-based) is the product over the tiles and pcg_tail(j) (miba_pcg.hpp), which is
+//   update(j):   alpha = rho_j / pq; x += alpha p; r -= alpha q; Q partials; z = M^-1 r; rho_{j+1} partials
+//   chkdir(j+1): end-of-iteration test of j (C_{j-1} -> C_j), then rho_{j+1}, beta, p = z + beta p
+// pcg_chkdir below is that second half as a kernel of its own; a solve launches it once, for j = 1 (p = z).
 // Every block recomputes the scalars from the same partial arrays in the same order, so all blocks (and all
 // ranks) take identical decisions.  part_rho is double-buffered by parity of the iteration that consumes it.
 
@@ -1195,74 +669,6 @@ __global__ __launch_bounds__(256) void pcg_chkdir(int j, size_t n, const double*
   if (bad) return;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     p[i] = (j == 1) ? z[i] : z[i] + beta * p[i];
-}
-
-// partial a.b (used when the mat-vec reduction cannot produce p.q itself: stored-J path, multi-GPU)
-__global__ __launch_bounds__(256) void pcg_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b,
-                                               const Ctl* __restrict__ ctl, double* __restrict__ part) {
-  __shared__ double s4[4];
-  if (ctl->done) return;
-  double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += a[i] * b[i];
-  const double s = block_sum(acc, s4);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
-}
-
-// MODE 0: x += alpha p, r -= alpha q, Q partials, z = M^-1 r, next rho partials
-// MODE 1: x += alpha p only (residual-reset iteration; r is rebuilt by MODE 2 after an extra mat-vec)
-// MODE 2: r = b - q (q = S x), Q partials, z = M^-1 r, next rho partials
-template <int MODE>
-__global__ __launch_bounds__(256) void pcg_update(int n_cam, const double* __restrict__ p, const double* __restrict__ q,
-                                                  const double* __restrict__ b, const double* __restrict__ Minv,
-                                                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
-                                                  const Ctl* __restrict__ ctl_cur, const double* __restrict__ part_rho_cur, int nb,
-                                                  const double* __restrict__ part_pq, int n_pq, double* __restrict__ part_q,
-                                                  double* __restrict__ part_rho_next) {
-  __shared__ double s_r[kPcgCams * 9];
-  __shared__ double s4[4];
-  if (ctl_cur->done) return;
-  const double rho = sum_partials(part_rho_cur, nb, s4);
-  const double pq = sum_partials(part_pq, n_pq, s4);
-  if (pq <= 0.0 || isinf(pq) || isnan(pq)) return;   // pcg_chkdir of the next iteration reports it
-  const double alpha = rho / pq;
-  if (isinf(alpha)) return;
-  const int tid = threadIdx.x;
-  const int cl = tid / 9, k = tid % 9;
-  double a_q = 0.0, a_rho = 0.0;
-  for (int c0 = blockIdx.x * kPcgCams; c0 < n_cam; c0 += gridDim.x * kPcgCams) {
-    const int c = c0 + cl;
-    const bool act = tid < kPcgCams * 9 && c < n_cam;
-    const size_t i = 9 * (size_t)c + k;
-    double rv = 0.0;
-    if (act) {
-      double xv;
-      if (MODE == 2) xv = x[i];
-      else { xv = x[i] + alpha * p[i]; x[i] = xv; }
-      if (MODE != 1) {
-        rv = (MODE == 0) ? r[i] - alpha * q[i] : b[i] - q[i];
-        r[i] = rv;
-        a_q += xv * (b[i] + rv);
-        s_r[tid] = rv;
-      }
-    }
-    if (MODE != 1) {
-      __syncthreads();
-      if (act) {
-        const double* m = Minv + 81 * (size_t)c + k;
-        double zz = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < 9; ++jj) zz += m[9 * jj] * s_r[9 * cl + jj];
-        z[i] = zz;
-        a_rho += rv * zz;
-      }
-      __syncthreads();
-    }
-  }
-  if (MODE != 1) {
-    const double sq = block_sum(a_q, s4);
-    const double sr = block_sum(a_rho, s4);
-    if (tid == 0) { part_q[blockIdx.x] = sq; part_rho_next[blockIdx.x] = sr; }
-  }
 }
 
 }  // namespace miba

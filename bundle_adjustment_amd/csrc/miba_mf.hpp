@@ -517,28 +517,6 @@ __device__ __forceinline__ void mf_grad_norms(const double* a, double& gmax, dou
   g2 += a[6] * a[6] + a[7] * a[7] + a[8] * a[8];
 }
 
-// camera-row contribution of one observation: upper triangle of F'F (45), F'v (9), F'r (9); ATOMIC: LDS accumulate
-template <bool ATOMIC>
-__device__ __forceinline__ void mf_cam_row(double* dst, const double* F, double v0, double v1, double r0, double r1) {
-  int o = 0;
-#pragma unroll
-  for (int i = 0; i < 9; ++i)
-#pragma unroll
-    for (int j = i; j < 9; ++j) {
-      const double v = F[i] * F[j] + F[9 + i] * F[9 + j];
-      if (ATOMIC) atomicAdd(dst + o, v); else dst[o] = v;
-      ++o;
-    }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const double v = F[k] * v0 + F[9 + k] * v1;
-    const double u = F[k] * r0 + F[9 + k] * r1;
-    if (ATOMIC) { atomicAdd(dst + 45 + k, v); atomicAdd(dst + 54 + k, u); }
-    else { dst[45 + k] = v; dst[54 + k] = u; }
-  }
-  if (!ATOMIC) dst[63] = 0.0;
-}
-
 // residual and point block E = A R only (the point-side pass needs no F)
 __device__ __forceinline__ void mf_resid_E(const double* cd, double x0, double x1, double x2, double ox, double oy, double* E,
                                            double& r0, double& r1) {
@@ -659,11 +637,10 @@ __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __res
   if (lane == 0) row[63] = 0.0;
 }
 
-// K2-mf: residual, cost, per-point Schur elimination and per-camera sums straight from the state.
-// Column scaling is NOT applied to F here (the raw camera sums are scaled by k_cam_reduce64); the point
-// scaling sp enters through mf_point_solve.  partial_cost[tile] = 0.5 sum r^2.
-// ROWS = false: point side only (no F, no camera rows); k_mf_camrows takes X and z from the point records.
-template <bool GIANT, bool ROWS, bool LOSS>
+// K2-mf, point side: residual, cost and per-point Schur elimination straight from the state (no F, no camera rows:
+// k_mf_camrows takes X and z from the point records this kernel writes).  The point scaling sp enters through
+// mf_point_solve.  partial_cost[tile] = 0.5 sum r^2.
+template <bool GIANT, bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                  const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                  const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
@@ -672,12 +649,10 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
                                                  const double* __restrict__ cm, const double* __restrict__ X,
                                                  const double* __restrict__ sp, double inv_radius, double dmin, double dmax,
                                                  double* __restrict__ gp, double* __restrict__ dgp /*diag E'E, or null*/,
-                                                 double* __restrict__ ptrec, double* __restrict__ slab /*[rows][64]*/,
+                                                 double* __restrict__ ptrec,
                                                  double* __restrict__ partial /*[tile][4]: cost, max |g_p|, |g_p|^2*/,
                                                  Ctl* __restrict__ ctl, const Loss loss, double* __restrict__ omega /*[slot], LOSS*/) {
-  static_assert(!(ROWS && LOSS), "the loss weights enter the camera rows in k_mf_camrows (two-pass K2 only)");
   __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
-  __shared__ double s_acc[(GIANT || !ROWS) ? 1 : kMaxCamSlots * 63];
   __shared__ double s4[4];
   const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
   const Tile t = tiles[tile_id];
@@ -686,8 +661,6 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
   double cost = 0.0, gmax = 0.0, g2 = 0.0;   // gradient norms of the unscaled problem: g / sp
   if (!GIANT) {
     if (tid < t.ncs) mf_stage_cam_init(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm);
-    if (ROWS)
-      for (int i = tid; i < t.ncs * 63; i += kChunk) s_acc[i] = 0.0;
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
     const int nwl = t.nslot / kWave;
@@ -700,7 +673,7 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
       const int cs = (w >> 8) & 0xFF, pl = w & 0xFF;
       const int pos = valid ? ((w >> 16) & 0x7F) : 0, cnt = valid ? (w >> 23) : 1;
       const size_t p = (size_t)(gpt0 + pl);
-      double F[ROWS ? 18 : 1], E[6], r0 = 0.0, r1 = 0.0, v[9];
+      double E[6], r0 = 0.0, r1 = 0.0, v[9];
       double x0 = 0, x1 = 0, x2 = 0, s0 = 1, s1 = 1, s2 = 1;
 #pragma unroll
       for (int k = 0; k < 9; ++k) v[k] = 0.0;
@@ -711,8 +684,7 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         const double ox = oxy[chunk * (2 * kChunk) + l], oy = oxy[chunk * (2 * kChunk) + kChunk + l];
         double cd[kCamLds];
         mf_read_cam(cd, s_cam, cs);
-        if (ROWS) mf_blocks(cd, x0, x1, x2, ox, oy, F, E, r0, r1);
-        else mf_resid_E(cd, x0, x1, x2, ox, oy, E, r0, r1);
+        mf_resid_E(cd, x0, x1, x2, ox, oy, E, r0, r1);
         v[0] = E[0] * E[0] + E[3] * E[3];
         v[1] = E[1] * E[0] + E[4] * E[3];
         v[2] = E[1] * E[1] + E[4] * E[4];
@@ -760,18 +732,6 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
 #pragma unroll
           for (int k = 0; k < 3; ++k) rp[3 + k] = z[k];
         }
-        if (ROWS) {
-          const double v0 = r0 - (E[0] * z[0] + E[1] * z[1] + E[2] * z[2]);
-          const double v1 = r1 - (E[3] * z[0] + E[4] * z[1] + E[5] * z[2]);
-          mf_cam_row<true>(s_acc + 63 * cs, F, v0, v1, r0, r1);
-        }
-      }
-    }
-    if (ROWS) {
-      __syncthreads();
-      for (int i = tid; i < t.ncs * kK2W; i += kChunk) {
-        const int s = i >> 6, k = i & 63;
-        slab[(size_t)kK2W * slab_row[t.cam0 + s] + k] = (k < 63) ? s_acc[s * 63 + k] : 0.0;
       }
     }
   } else {
@@ -790,9 +750,9 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
 #pragma unroll
         for (int k = 0; k < 9; ++k) v[k] = 0.0;
         if (idx[slot] >= 0) {
-          double cd[kCamLds], F[18], E[6], r0, r1;
+          double cd[kCamLds], E[6], r0, r1;
           mf_stage_cam_init(cd, ocam[slot], ct, cm);
-          mf_blocks(cd, x0, x1, x2, oxy[chunk * (2 * kChunk) + tid], oxy[chunk * (2 * kChunk) + kChunk + tid], F, E, r0, r1);
+          mf_resid_E(cd, x0, x1, x2, oxy[chunk * (2 * kChunk) + tid], oxy[chunk * (2 * kChunk) + kChunk + tid], E, r0, r1);
           v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[1] * E[0] + E[4] * E[3]; v[2] = E[1] * E[1] + E[4] * E[4];
           v[3] = E[2] * E[0] + E[5] * E[3]; v[4] = E[2] * E[1] + E[5] * E[4]; v[5] = E[2] * E[2] + E[5] * E[5];
           v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
@@ -827,17 +787,6 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
         for (int k = 0; k < 6; ++k) rp[6 + k] = W[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) rp[3 + k] = z[k];
-      }
-      for (int ch = 0; ROWS && ch < G.nchunk; ++ch) {
-        const size_t chunk = (size_t)(G.chunk0 + ch);
-        const size_t slot = chunk * kChunk + tid;
-        if (idx[slot] < 0) continue;
-        double cd[kCamLds], F[18], E[6], r0, r1;
-        mf_stage_cam_init(cd, ocam[slot], ct, cm);
-        mf_blocks(cd, x0, x1, x2, oxy[chunk * (2 * kChunk) + tid], oxy[chunk * (2 * kChunk) + kChunk + tid], F, E, r0, r1);
-        const double v0 = r0 - (E[0] * z[0] + E[1] * z[1] + E[2] * z[2]);
-        const double v1 = r1 - (E[3] * z[0] + E[4] * z[1] + E[5] * z[2]);
-        mf_cam_row<false>(slab + (size_t)kK2W * slab_row[t.cam0 + (int)(slot - (size_t)t.slot0)], F, v0, v1, r0, r1);
       }
     }
   }

@@ -291,9 +291,10 @@ void BundleAdjustment::solve() {
                                         ? "ITERATIVE_SCHUR (HIP implicit-Schur PCG, SCHUR_JACOBI preconditioner)"
                                         : "ITERATIVE_SCHUR (HIP implicit-Schur PCG, JACOBI preconditioner)")
                                  : ms.exact_linear_solver
-                                       ? "DENSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device)"
+                                       ? "DENSE_SCHUR / SPARSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device: dense up to "
+                                         "2048 cameras, 64 x 64 tiles of the sparse Schur complement beyond)"
                                        : "ITERATIVE_SCHUR (HIP implicit-Schur PCG run to q-tolerance 1e-12 in place of the exact solver: "
-                                         "more than 2048 cameras, or MIBA_DENSE=0 / MIBA_MF=0)";
+                                         "the tiles of the Schur complement do not fit the free device memory, or MIBA_DENSE=0)";
 
     std::cout << ceres::LinearSolverTypeToString(options.linear_solver_type) << std::endl;
     std::cout << summary.FullReport() << std::endl;

@@ -139,8 +139,7 @@ typedef struct {
   double max_solver_time_in_seconds;        /* 1e9 */
   /* robust loss applied to every residual block: the LossFunction argument of Problem::AddResidualBlock, for which
    * the reference passes nullptr (src/BundleAdjustment.cpp:69) = MIBA_LOSS_NONE, the default.  HUBER / CAUCHY are
-   * ceres::HuberLoss(loss_scale) / ceres::CauchyLoss(loss_scale); every linear solver type and preconditioner,
-   * matrix-free two-pass kernels only (refused with MIBA_MF=0 or MIBA_K2_ONEPASS=1). */
+   * ceres::HuberLoss(loss_scale) / ceres::CauchyLoss(loss_scale); every linear solver type and preconditioner. */
   int32_t loss_type;
   int32_t reserved;
   double loss_scale;                        /* the 'a' of HuberLoss / CauchyLoss, in residual units (pixels) */

@@ -160,7 +160,7 @@ def test_synthetic_50k_properties():
     used_gb = (free0 - free1) / 1e9
     # no stored Jacobian (it would be 31.8 GB): ~13 GB of indices, measurements, point blocks (with the default point order;
     # MIBA_POINT_ORDER=0 gives up the camera locality of the tiles and pays for it in slab rows: 37 GB)
-    if os.environ.get("MIBA_POINT_ORDER", "1") != "0" and os.environ.get("MIBA_MF", "1") != "0":
+    if os.environ.get("MIBA_POINT_ORDER", "1") != "0":
         assert 8.0 < used_gb < 20.0, used_gb
     its, summ = s.solve(miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, max_num_iterations=4,
                                              function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))

@@ -122,7 +122,7 @@ def test_run_to_run_reproducibility(solver):
         assert len(its) == len(its0)
         for a, b in zip(its, its0):
             assert a["step_is_successful"] == b["step_is_successful"]
-            # (MIBA_MF=0 / MIBA_DENSE=0 replace the exact solve by PCG to q-tolerance 1e-12, whose stopping test sits in
+            # (MIBA_DENSE=0 replaces the exact solve by PCG to q-tolerance 1e-12, whose stopping test sits in
             # rounding noise: its length wanders by a few iterations from run to run)
             if solver != "exact" or b["linear_solver_iterations"] <= 1:
                 assert a["linear_solver_iterations"] == b["linear_solver_iterations"]

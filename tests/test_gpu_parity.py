@@ -252,23 +252,6 @@ def _solve_with_env(pr, cams0, pts0, env, n_it=8):
     return out, its, summ
 
 
-def test_matrix_free_matches_stored_jacobian(medium):
-    """The default matrix-free kernels (K2-mf/K3-mf/K4-mf) against the stored-Jacobian kernels (MIBA_MF=0):
-    same operator, same right-hand side, same PCG iteration counts, same LM trajectory."""
-    pr, cams0, pts0 = medium
-    a, ia, sa = _solve_with_env(pr, cams0, pts0, {"MIBA_MF": "1"})
-    b, ib, sb = _solve_with_env(pr, cams0, pts0, {"MIBA_MF": "0"})
-    assert rel(a["rhs"], b["rhs"]) <= 1e-11
-    assert rel(a["Sv"], b["Sv"]) <= 1e-11
-    assert a["n_cg"] == b["n_cg"]
-    assert rel(a["y_cam"], b["y_cam"]) <= 1e-9 and rel(a["y_pt"], b["y_pt"]) <= 1e-9
-    assert abs(a["model_cost_change"] - b["model_cost_change"]) <= 1e-10 * abs(b["model_cost_change"])
-    for x, y in zip(ia[:5], ib[:5]):
-        assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
-        assert x["linear_solver_iterations"] == y["linear_solver_iterations"]
-    assert abs(sa["final_cost"] - sb["final_cost"]) <= REL_COST * sb["final_cost"]
-
-
 @pytest.mark.parametrize("tile_chunks", ["1", "3", "16"])
 def test_tile_size_does_not_change_results(medium, tile_chunks):
     """MIBA_TILE_CHUNKS only changes how observations are grouped into workgroup tiles."""
@@ -287,17 +270,6 @@ def test_rccl_path_single_rank(medium):
     b, ib, sb = _solve_with_env(pr, cams0, pts0, {"MIBA_FORCE_RCCL": "1"})
     assert rel(a["Sv"], b["Sv"]) <= 1e-12 and rel(a["y_cam"], b["y_cam"]) <= 1e-9
     assert [r["linear_solver_iterations"] for r in ia[:5]] == [r["linear_solver_iterations"] for r in ib[:5]]
-    assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
-
-
-def test_k2_one_pass_matches_two_pass(medium):
-    """K2-mf camera rows by LDS atomics in one pass (MIBA_K2_ONEPASS=1) against the default two-pass form
-    (point side over wavelets, camera side over the camera-major observation copy)."""
-    pr, cams0, pts0 = medium
-    a, ia, sa = _solve_with_env(pr, cams0, pts0, {})
-    b, ib, sb = _solve_with_env(pr, cams0, pts0, {"MIBA_K2_ONEPASS": "1"})
-    assert rel(a["rhs"], b["rhs"]) <= 1e-11 and rel(a["Sv"], b["Sv"]) <= 1e-11
-    assert a["n_cg"] == b["n_cg"]
     assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
 
 

@@ -109,7 +109,7 @@ def test_app_main_end_to_end(tmp_path, oracle):
     last = max(int(f[len("mesh_SPARSE_SCHUR_"):-4]) for f in dumps)
     assert open(tmp_path / ("mesh_SPARSE_SCHUR_%d.ply" % last)).read() == open(tmp_path / "constrainTransReal.ply").read()
     # a factorisation-based solver type on a small problem is served by the device Cholesky, and the report says so
-    if os.environ.get("MIBA_MF", "1") != "0" and os.environ.get("MIBA_DENSE", "1") != "0":
+    if os.environ.get("MIBA_DENSE", "1") != "0":
         assert "blocked Cholesky on the device" in out.stdout, out.stdout[-2000:]
 
 
@@ -138,8 +138,6 @@ def test_app_main_with_loss_function(tmp_path, oracle):
     """BA_LOSS=huber:1.5: the LossFunction argument of AddResidualBlock, nullptr in the reference
     (src/BundleAdjustment.cpp:69), set to ceres::HuberLoss(1.5) for a file with gross outliers; final cost against
     the oracle with the same loss."""
-    if os.environ.get("MIBA_MF", "1") == "0" or os.environ.get("MIBA_K2_ONEPASS", "0") == "1":
-        pytest.skip("the loss lives in the two-pass matrix-free kernels")
     pr = synth.make_problem(20, 600, 2600, seed=5)
     oxy = pr["obs_xy"].copy()
     oxy[::8] += np.random.default_rng(2).normal(0, 35.0, oxy[::8].shape)

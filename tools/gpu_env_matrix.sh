@@ -11,10 +11,6 @@ run MIBA_POINT_ORDER=0 || exit 1
 run MIBA_FORCE_RCCL=1 || exit 1
 run MIBA_DENSE_PLAN=0 || exit 1
 run MIBA_DEVICE_PLAN=0 || exit 1
-# the exact solve and SCHUR_JACOBI need the two-pass matrix-free kernels: the tests that use them are skipped for these three
-# (so do the loss functions: tests/test_gpu_loss.py is left out for the first two)
-EXTRA="--deselect tests/test_gpu_dense.py --deselect tests/test_gpu_multirank.py --deselect tests/test_gpu_loss.py"
-run MIBA_K2_ONEPASS=1 || exit 1
-run MIBA_MF=0 || exit 1
-EXTRA="--deselect tests/test_gpu_dense.py --deselect tests/test_gpu_multirank.py"
+# the tests of the exact solve and the multi-rank runs that use it are left out when it is switched off
+EXTRA="--deselect tests/test_gpu_dense.py --deselect tests/test_gpu_sparse.py --deselect tests/test_gpu_multirank.py"
 run MIBA_DENSE=0 || exit 1

@@ -14,5 +14,5 @@ probe = np.random.default_rng(1).normal(size=(n_cam, 9))
 out = s.linear_step(1e4, miba.default_options(max_linear_solver_iterations=int(os.environ.get("PCG_ITS", "2")), eta=1e-30), probe=probe)
 ms = [s.time_matvec(probe, reps) for _ in range(3)]
 kt = s.kernel_times()
-print(json.dumps({"mf": os.environ.get("MIBA_MF", "0"), "tile_chunks": os.environ.get("MIBA_TILE_CHUNKS", "4"), "matvec_ms": ms,
+print(json.dumps({"tile_chunks": os.environ.get("MIBA_TILE_CHUNKS", "4"), "matvec_ms": ms,
                   "Sv_norm": float(np.linalg.norm(out["Sv"])), "slots": kt["n_slots"], "tiles": kt["n_tiles"]}))
