@@ -1145,9 +1145,10 @@ int sparse_solve(miba_handle h, int* status) {
   for (int k = 0; k < nT; ++k) {
     const int64_t c0 = h->sp_col_ptr[k];
     const int cnt = (int)(h->sp_col_ptr[k + 1] - c0);   // diagonal, tiles below it, right-hand side
-    hipLaunchKernelGGL(k_tchol_panel, dim3(cnt), dim3(kNB), 0, h->st, T, (const int32_t*)(h->d_sp_col_slots + c0), h->d_sp_Ldiag + (size_t)k * 4096,
-                       (int*)h->d_dflag);
-    const int m = cnt - 1;
+    double* W = h->d_sp_Ldiag + (size_t)k * 4096;
+    hipLaunchKernelGGL(k_tchol_diag, dim3(1), dim3(kNB), 0, h->st, (const double*)T, (const int32_t*)(h->d_sp_col_slots + c0), W, (int*)h->d_dflag);
+    const int m = cnt - 1;   // tiles below the diagonal, the right-hand-side tile among them
+    hipLaunchKernelGGL(k_tchol_panel, dim3(m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const double*)W);
     if (m > 1)
       hipLaunchKernelGGL(k_tchol_update, dim3(m, m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_rows + c0 + 1),
                          (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const int32_t*)h->d_sp_map, nT);

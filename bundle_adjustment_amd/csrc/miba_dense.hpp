@@ -406,8 +406,14 @@ __device__ __forceinline__ bool chol_diag_wave(const double* __restrict__ diag /
     const double l = (lane >= j) ? a[j] * rd : 0.0;
     Lt[j * kLs + lane] = l;
     if (lane == 0) Lr[j] = rd;
+    // all operands of the step are requested before the first FMA (the reads pipeline in the LDS; taken one by one, each
+    // costs its round trip)
+    double t[kNB];
 #pragma unroll
-    for (int c = j + 1; c < kNB; ++c) a[c] = fma(-l, Lt[j * kLs + c], a[c]);
+    for (int c = j + 1; c < kNB; ++c) t[c] = Lt[j * kLs + c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = j + 1; c < kNB; ++c) a[c] = fma(-l, t[c], a[c]);
     // pin the row after every step: left alone, the compiler turns the unrolled nest into one deferred dot product
     // per column, keeps every earlier column live for it and spills
 #pragma unroll
@@ -443,8 +449,12 @@ __global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ S, int N
   for (int k = 0; k < kNB; ++k) {
     const double xk = x[k] * Lr[k];
     x[k] = xk;
+    double t[kNB];   // (operands requested together, as in chol_diag_wave)
 #pragma unroll
-    for (int c = k + 1; c < kNB; ++c) x[c] = fma(-xk, Lt[k * kLs + c], x[c]);
+    for (int c = k + 1; c < kNB; ++c) t[c] = Lt[k * kLs + c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = k + 1; c < kNB; ++c) x[c] = fma(-xk, t[c], x[c]);
 #pragma unroll
     for (int c = k + 1; c < kNB; ++c) asm volatile("" : "+v"(x[c]));
   }

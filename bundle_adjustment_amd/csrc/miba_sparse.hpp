@@ -21,40 +21,65 @@ __device__ __forceinline__ void tchol_row_solve(double* x, const double* Lt, con
   for (int k = 0; k < kNB; ++k) {
     const double xk = x[k] * Lr[k];
     x[k] = xk;
+    double t[kNB];
 #pragma unroll
-    for (int c = k + 1; c < kNB; ++c) x[c] = fma(-xk, Lt[k * kLs + c], x[c]);
+    for (int c = k + 1; c < kNB; ++c) t[c] = Lt[k * kLs + c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = k + 1; c < kNB; ++c) x[c] = fma(-xk, t[c], x[c]);
 #pragma unroll
     for (int c = k + 1; c < kNB; ++c) asm volatile("" : "+v"(x[c]));
   }
 }
 
-// column step k: every workgroup (one wave) factors the diagonal tile itself; workgroup b > 0 solves panel tile b of the column
-// (slots[0] = the diagonal tile, slots[1..] the tiles below it, the right-hand-side tile last); workgroup 0 solves the identity
-// instead, which gives W = L^-T, the operator of the backward substitution: Winv[c * 64 + i] = W[i][c]
-__global__ __launch_bounds__(64) void k_tchol_panel(double* __restrict__ tiles, const int32_t* __restrict__ slots /*of this column*/,
-                                                    double* __restrict__ Winv /*[64 * 64]*/, int* __restrict__ flag) {
+// Column step k, first launch (one wave): Cholesky factor L of the diagonal tile (chol_diag_wave, miba_dense.hpp), then
+// W = L^-T by solving x L' = e_lane against it.  Only W leaves the kernel (Winv[c * 64 + i] = W[i][c]): the panel tiles are
+// multiplied by it on the matrix cores (k_tchol_panel), and the backward substitution uses it too; the factor of the diagonal
+// tile itself is never needed again.  (One sweep for both, sharing the LDS operands, would save a third of the time; the
+// doubly unrolled 64-step nest does not get through the compiler in a quarter of an hour.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_diag(const double* __restrict__ tiles, const int32_t* __restrict__ slots /*of this column*/,
+                                                   double* __restrict__ Winv /*[64 * 64]*/, int* __restrict__ flag) {
   __shared__ __align__(16) double Lt[kNB * kLs];
   __shared__ double Lr[kNB];
   const int lane = threadIdx.x;
-  {
-    const bool bad = chol_diag_wave(tiles + (size_t)slots[0] * 4096, 64, lane, Lt, Lr);
-    if (bad && blockIdx.x == 0 && lane == 0) *flag = 1;
-  }
+  const bool bad = chol_diag_wave(tiles + (size_t)slots[0] * 4096, 64, lane, Lt, Lr);
+  if (bad && lane == 0) *flag = 1;
   double x[kNB];
-  if (blockIdx.x == 0) {
 #pragma unroll
-    for (int c = 0; c < kNB; ++c) x[c] = (c == lane) ? 1.0 : 0.0;
-    tchol_row_solve(x, Lt, Lr);
-#pragma unroll
-    for (int c = 0; c < kNB; ++c) Winv[c * kNB + lane] = x[c];
-    return;
-  }
-  double* row = tiles + (size_t)slots[blockIdx.x] * 4096 + (size_t)lane * 64;
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) x[c] = row[c];
+  for (int c = 0; c < kNB; ++c) x[c] = (c == lane) ? 1.0 : 0.0;
   tchol_row_solve(x, Lt, Lr);
 #pragma unroll
-  for (int c = 0; c < kNB; ++c) row[c] = x[c];
+  for (int c = 0; c < kNB; ++c) Winv[c * kNB + lane] = x[c];
+}
+
+// Column step k, second launch: panel tile b of the column (slots[b]: the tiles below the diagonal, the right-hand-side tile
+// last) becomes X = A W = A L^-T on the fp64 matrix cores: wave = 16 rows, A fragment lane l = A[l & 15][4 kk + (l >> 4)],
+// B[k][n] = W[k][16 nt + n] = Winv[(16 nt + n) * 64 + k], D: row (l >> 4) + 4 reg, column l & 15.  In place: a wave reads all
+// of its sixteen rows before it writes any of them, and nobody else touches them.
+__global__ __launch_bounds__(256) void k_tchol_panel(double* __restrict__ tiles, const int32_t* __restrict__ slots, const double* __restrict__ Winv) {
+  __shared__ double wt[kNB][kNB + 1];
+  const int tid = threadIdx.x;
+  double* A = tiles + (size_t)slots[blockIdx.x] * 4096;
+  for (int i = tid; i < kNB * kNB; i += 256) wt[i >> 6][i & 63] = Winv[i];
+  const int l = tid & 63, wv = tid >> 6;
+  const int ar = l & 15, ak = l >> 4;
+  double af[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
+  __syncthreads();
+  d4_t c[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    c[nt] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) c[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], wt[16 * nt + ar][4 * kk + ak], c[nt], 0, 0, 0);
+  }
+  // (the wave's rows are all in af and c by now: the stores below cannot reach a value another lane of the wave still needs,
+  // MFMA operands are read when the instruction issues)
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) A[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] = c[nt][reg];
 }
 
 // trailing update of column step k: tile (r_I, r_J) -= L(r_I, k) L(r_J, k)' for the tiles I >= J below the diagonal of the
@@ -79,13 +104,18 @@ __global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles
   double af[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
+  // the destination is requested together with the operands (one trip to memory, not two), negated as the accumulator's start
+  d4_t c[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) c[nt][reg] = -Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    d4_t c = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bt[16 * nt + ar][4 * kk + ak], c, 0, 0, 0);
+    for (int kk = 0; kk < 16; ++kk) c[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bt[16 * nt + ar][4 * kk + ak], c[nt], 0, 0, 0);
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] -= c[reg];
+    for (int reg = 0; reg < 4; ++reg) Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] = -c[nt][reg];
   }
 }
 
