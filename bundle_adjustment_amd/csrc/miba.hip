@@ -688,7 +688,7 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
   A.ctl = h->d_ctl;
   // one rank: the tail's own p.q partials; several ranks: the camera reduction's, behind q so that one all-reduce takes both
   A.part_pq = multi ? h->d_pq + n : h->d_part_pcg + 4 * kPcgMaxBlocks;
-  A.n_pq = multi ? h->red_nb : nb;
+  A.n_pq = nb;
   A.part_q = part_q; A.part_rho0 = part_rho[0]; A.part_rho1 = part_rho[1];
   A.q_tol = q_tol; A.min_it = min_it; A.max_it = max_it;
   A.bar = h->d_bar;
@@ -701,16 +701,17 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
                      A.n_pq, part_q, q_tol, min_it, max_it);
   HIPCHK(h, hipGetLastError());
   if (check_every < 1) check_every = 1;
-  // camera-side sum and all-reduce as launches of their own (several ranks)
-  auto reduce_step = [&](const double* v, bool with_pq, int j, bool sample) -> int {
+  // camera-side sum (phase A of the tail as a launch of its own: this rank's slab rows) and all-reduce (several ranks)
+  auto reduce_step = [&](bool on_x, int j, bool sample) -> int {
     {
       Timed t(h, MIBA_K_CAM_REDUCE, j, sample);
-      hipLaunchKernelGGL(k_cam_reduce_mf, dim3(h->red_nb), dim3(256), 0, h->st, h->n_cam, h->red_cpb, h->d_cam_row_off, h->d_slab9,
-                         h->d_ct, h->d_cm, h->d_sc, h->d_Dc2, v, A.diag_w, h->d_pq, with_pq ? A.part_pq : (double*)nullptr,
-                         h->d_ctl + ((j - 1) & 1));
+      TailArgs R = A;
+      R.j = j;
+      R.a_on_x = on_x ? 1 : 0;
+      hipLaunchKernelGGL((pcg_tail<3, true>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, R);
     }
     HIPCHK(h, hipGetLastError());
-    return allreduce(h, h->d_pq, n + (with_pq ? (size_t)h->red_nb : 0), ncclSum);
+    return allreduce(h, h->d_pq, n + (on_x ? 0 : (size_t)nb), ncclSum);
   };
   for (int j = 1;; ++j) {
     Ctl* cur = h->d_ctl + ((j - 1) & 1);   // C_{j-1}: state after the j-1 iterations tested so far
@@ -729,7 +730,7 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
     A.j = j;
     int rc = MIBA_OK;
     mf_matvec_tiles(h, h->d_pp, cur, j, sample);
-    if (multi && (rc = reduce_step(h->d_pp, true, j, sample))) return rc;
+    if (multi && (rc = reduce_step(false, j, sample))) return rc;
     if (!reset) {
       Timed t(h, multi ? -1 : MIBA_K_CAM_REDUCE, j, sample && !multi);
       launch_tail<0>(h, A, !multi);
@@ -737,7 +738,7 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
       launch_tail<1>(h, A, !multi);
       HIPCHK(h, hipGetLastError());
       mf_matvec_tiles(h, h->d_px, cur, j, sample);   // q = S p is dead once x is updated: reuse it for S x
-      if (multi && (rc = reduce_step(h->d_px, false, j, false))) return rc;
+      if (multi && (rc = reduce_step(true, j, false))) return rc;
       launch_tail<2>(h, A, !multi);
     }
     HIPCHK(h, hipGetLastError());

@@ -134,6 +134,7 @@ struct TailArgs {
   double* part_q;      // partials of Q, one per workgroup
   double* part_rho0; double* part_rho1;   // partials of rho_k in part_rho[k & 1]
   double q_tol; int min_it, max_it;
+  int a_on_x;          // MODE 3: the product's input is x (residual refresh), not p
   unsigned* bar;       // barrier counters
   long long* dbg;      // MIBA_TAIL_DEBUG: [workgroup][8] time stamps of the phases (100 MHz counter), else null
 };
@@ -157,6 +158,8 @@ __device__ __forceinline__ void tail_sum_partials2(const double* pa, int na, con
 // MODE 0: the whole tail of iteration j.
 // MODE 1: residual-reset iteration, first half: A, alpha, x += alpha p (r is rebuilt from S x by MODE 2 after another product).
 // MODE 2: second half: A on q = S x (no p.q), r = b - q, Q, z, r.z, then C.
+// MODE 3: phase A alone (several ranks: the all-reduce of q and of the p.q partials behind it follows, then the tail without
+//         REDUCE): q = S v of this rank's slab rows, v = x when a_on_x is set (no partials then), else p.
 // REDUCE: phase A is part of this launch (one rank); otherwise q and the p.q partials are there already.
 //
 // Lane (sub, k) of a wave owns entry k of camera cam0 + sub (cpw cameras per wave, nine lanes each).  When one round covers all
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   Ctl c = a.ctl[(j - 1) & 1];   // C_{j-1}
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   if (c.done) {
-    if (writer && MODE != 1) a.ctl[j & 1] = c;   // the final state in both buffers
+    if (writer && MODE != 1 && MODE != 3) a.ctl[j & 1] = c;   // the final state in both buffers
     return;
   }
   TAIL_STAMP(0);
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
 
   // ---- A: q = S v over the cameras of this wave (v = p, or x in MODE 2) ----
   if (REDUCE) {
-    const double* v_in = (MODE == 2) ? a.x : a.p;
+    const double* v_in = (MODE == 2 || (MODE == 3 && a.a_on_x)) ? a.x : a.p;
     double xy = 0.0;
     double* wp = s_wp + (size_t)wv * 7 * 64;
     int* bnd = s_bnd + wv * 8;
@@ -258,10 +261,17 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
         double rr = cf[0] * v0 + cf[1] * v1 + cf[2] * v2 + cf[3] * v3 + cf[4] * v4 + cf[5] * v5 + cf[6] * tot;
         rr *= scv;
         rr += a.diag_w * d2v * xv;
-        if (single) { c_q = rr; if (MODE != 2) c_p = xv; else c_x = xv; }
+        if (single && MODE != 3) { c_q = rr; if (MODE != 2) c_p = xv; else c_x = xv; }
         else a.q[i] = rr;
         xy += xv * rr;
       }
+    }
+    if (MODE == 3) {
+      if (!a.a_on_x) {
+        const double s = tail_block_sum(xy, s32);
+        if (tid == 0) a.part_pq[blockIdx.x] = s;
+      }
+      return;
     }
     if (MODE != 2) {
       const double s = tail_block_sum(xy, s32);
