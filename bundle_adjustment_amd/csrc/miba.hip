@@ -1555,8 +1555,9 @@ int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* ow
 // radix sort.  Returns non-zero (the planner then sorts on its host threads) when the device cannot hold the scratch.
 struct DeviceSortCtx { int device; hipStream_t st; };
 static int device_plan_sort(void* ctx, int64_t n_obs, int32_t n_pt, const int32_t* obs_cam, const int32_t* obs_pt, const uint8_t* ok,
-                            const int32_t* sorted_of, int32_t n_act, int64_t n_valid, int64_t* obs_sorted) {
+                            const int32_t* sorted_of, int32_t n_act, int64_t n_valid, int64_t* obs_sorted, int32_t* sorted_cam) {
   const DeviceSortCtx& C = *(const DeviceSortCtx*)ctx;
+  PlanLap lap;
   if (n_obs < 1 || n_obs >= ((int64_t)1 << 32) || hipSetDevice(C.device) != hipSuccess) return 1;
   const size_t n = (size_t)n_obs;
   int32_t *d_cam = nullptr, *d_pt = nullptr, *d_so = nullptr;
@@ -1589,15 +1590,23 @@ static int device_plan_sort(void* ctx, int64_t n_obs, int32_t n_pt, const int32_
   while (end_bit < 64 && ((uint64_t)1 << (end_bit - 24)) < (uint64_t)std::max<int32_t>(1, n_act)) ++end_bit;
   if (n_valid != n_obs) end_bit = 64;
   if (e == hipSuccess) e = device_sort_pairs(k0, k1, v0, v1, n, end_bit, C.st);
-  std::vector<uint32_t> out;
+  raw_vector<uint32_t> out;
+  if (e == hipSuccess) {
+    // the cameras in sorted order are the low 24 bits of the sorted keys (d_cam has served its purpose and takes them)
+    hipLaunchKernelGGL(k_key_cam, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, C.st, n_valid, k1, d_cam);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) {
     out.resize((size_t)n_valid);
     e = hipMemcpyAsync(out.data(), v1, (size_t)n_valid * 4, hipMemcpyDeviceToHost, C.st);
+    if (e == hipSuccess) e = hipMemcpyAsync(sorted_cam, d_cam, (size_t)n_valid * 4, hipMemcpyDeviceToHost, C.st);
     if (e == hipSuccess) e = hipStreamSynchronize(C.st);
   }
+  lap("  device sort (upload, sort, download)");
   cleanup();
   if (e != hipSuccess) { (void)hipGetLastError(); return 1; }
   plan_parallel_for(n_valid, [&](int64_t a, int64_t b) { for (int64_t j = a; j < b; ++j) obs_sorted[j] = (int64_t)out[(size_t)j]; });
+  lap("  free + widen");
   return 0;
 }
 
@@ -1913,11 +1922,12 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   HIPCHK(h, hipStreamSynchronize(h->st));
   // the big host-side index arrays are not needed any more, except slot_orig / pt_orig (evaluate, get_state)
   if (!shared) {
-    std::vector<int32_t>().swap(P.idx);
-    std::vector<int32_t>().swap(P.ocam);
+    decltype(P.idx)().swap(P.idx);
+    decltype(P.ocam)().swap(P.ocam);
   }
   h->has_problem = true;
   memset(&h->kt, 0, sizeof(h->kt));
+  lap("finish");
   if (h->cam_model == MIBA_MODEL_REFERENCE) {   // all blocks free, except the intrinsics of the reference's model (src/BundleAdjustment.cpp:77)
     rc = miba_set_constant_blocks(h, nullptr);
     if (rc) { free_problem(h); return rc; }
@@ -1937,8 +1947,8 @@ int miba_set_problem(miba_handle h, const miba_problem* p) {
                                device_repack_wanted() ? &sorter : nullptr);
     if (prc) return fail(h, prc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d): indices out of range or limits exceeded", prc);
     const int rc = group_run(h, [&](miba_handle s, int) { return set_problem_impl(s, p, P); });
-    std::vector<int32_t>().swap(P->idx);
-    std::vector<int32_t>().swap(P->ocam);
+    decltype(P->idx)().swap(P->idx);
+    decltype(P->ocam)().swap(P->ocam);
     h->has_problem = rc == MIBA_OK;
     return rc;
   }

@@ -14,11 +14,13 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <chrono>
 #include <cstdio>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace miba {
@@ -37,6 +39,17 @@ inline void plan_parallel_for(int64_t n, F fn, int64_t min_parallel = (1 << 16))
   fn(0, n / t);
   for (auto& x : th) x.join();
 }
+
+// std::vector whose resize() leaves new elements uninitialised: the planner's big arrays (one entry per observation) are
+// filled by its worker threads, and a value-initialising resize would first fault in and zero every page on one thread
+template <typename T>
+struct default_init_alloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = default_init_alloc<U>; };
+  using std::allocator<T>::allocator;
+  template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <typename T> using raw_vector = std::vector<T, default_init_alloc<T>>;
 
 // MIBA_DEBUG_PLAN=1: phase times of the host tiler on stderr
 struct PlanLap {
@@ -84,9 +97,9 @@ struct Plan {
   // global tiling (all shards)
   std::vector<Tile> tiles;
   std::vector<Group> groups;
-  std::vector<int32_t> idx;              // [n_slots] pl | cs<<8, -1 = pad
-  std::vector<int32_t> ocam;             // [n_slots] global camera id (0 for pads)
-  std::vector<int64_t> slot_orig;        // [n_slots] caller's observation index, -1 = pad
+  raw_vector<int32_t> idx;               // [n_slots] pl | cs<<8, -1 = pad
+  raw_vector<int32_t> ocam;              // [n_slots] global camera id (0 for pads)
+  raw_vector<int64_t> slot_orig;         // [n_slots] caller's observation index, -1 = pad
   std::vector<int32_t> pt_first;         // [n_pt] first slot of sorted point
   std::vector<int32_t> pt_count;         // [n_pt]
   std::vector<int32_t> tile_cams;        // per (tile, cam slot): global camera id
@@ -98,10 +111,11 @@ struct Plan {
 
 // point_order: 0 = caller's order, 1 = sort by smallest camera index (camera locality)
 // optional sorter of build_plan: fills obs_sorted[n_valid] with the indices of the valid observations ordered by
-// (sorted_of[obs_pt], obs_cam), stable; returns 0, or non-zero to make build_plan use its host sort
+// (sorted_of[obs_pt], obs_cam), stable, and sorted_cam[n_valid] with their cameras in that order; returns 0, or non-zero to
+// make build_plan use its host sort
 struct PlanSorter {
   int (*fn)(void* ctx, int64_t n_obs, int32_t n_pt, const int32_t* obs_cam, const int32_t* obs_pt, const uint8_t* ok,
-            const int32_t* sorted_of /*[n_pt]*/, int32_t n_act, int64_t n_valid, int64_t* obs_sorted);
+            const int32_t* sorted_of /*[n_pt]*/, int32_t n_act, int64_t n_valid, int64_t* obs_sorted, int32_t* sorted_cam);
   void* ctx;
 };
 
@@ -186,10 +200,12 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   // observations of every sorted point, ascending camera, file order among equal cameras: a stable sort of the valid
   // observations by (sorted point, camera).  On the GPU when the caller brings a sorter (miba_set_problem: rocPRIM radix
   // sort), else bucket + per-point sort on the host threads; both give the same permutation.
-  std::vector<int64_t> obs_sorted(P.n_valid ? P.n_valid : 1);
+  raw_vector<int64_t> obs_sorted(P.n_valid ? P.n_valid : 1);
+  raw_vector<int32_t> sorted_cam(P.n_valid ? P.n_valid : 1);
   bool sorted_on_device = false;
   if (sorter && sorter->fn && P.n_valid > 0)
-    sorted_on_device = sorter->fn(sorter->ctx, n_obs, n_pt, obs_cam, obs_pt, ok.data(), sorted_of.data(), n_act, P.n_valid, obs_sorted.data()) == 0;
+    sorted_on_device = sorter->fn(sorter->ctx, n_obs, n_pt, obs_cam, obs_pt, ok.data(), sorted_of.data(), n_act, P.n_valid, obs_sorted.data(),
+                                  sorted_cam.data()) == 0;
   if (!sorted_on_device) {
     std::vector<int64_t> cur(off.begin(), off.end() - 1);
     for (int64_t i = 0; i < n_obs; ++i)
@@ -199,11 +215,10 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
         std::stable_sort(obs_sorted.begin() + off[s], obs_sorted.begin() + off[s + 1],
                          [&](int64_t a, int64_t b) { return obs_cam[a] < obs_cam[b]; });
     });
+    plan_parallel_for(P.n_valid, [&](int64_t a, int64_t b) {
+      for (int64_t j = a; j < b; ++j) sorted_cam[j] = obs_cam[obs_sorted[j]];
+    });
   }
-  std::vector<int32_t> sorted_cam(P.n_valid ? P.n_valid : 1);
-  plan_parallel_for(P.n_valid, [&](int64_t a, int64_t b) {
-    for (int64_t j = a; j < b; ++j) sorted_cam[j] = obs_cam[obs_sorted[j]];
-  });
   lap("bucket + per-point sort");
   // --- tiling, phase 1: cut the point sequence into tiles.  A tile holds whole points, at most kMaxCamSlots
   // distinct cameras and about max_chunks chunks of observations; a giant point (more observations than a
@@ -319,9 +334,9 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
         for (int64_t j = a; j < b; ++j) {
           const int64_t i = obs_sorted[j];
           Q.idx.push_back(0);
-          Q.ocam.push_back(obs_cam[i]);
+          Q.ocam.push_back(sorted_cam[j]);
           Q.slot_orig.push_back(i);
-          Q.tile_cams.push_back(obs_cam[i]);
+          Q.tile_cams.push_back(sorted_cam[j]);
           ++slots;
         }
         pad_to(kChunk);
@@ -362,7 +377,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
               Q.new_orig.push_back(P.pt_orig[s]);
               for (int64_t j = a; j < b; ++j) {
                 const int64_t i = obs_sorted[j];
-                const int32_t c = obs_cam[i];
+                const int32_t c = sorted_cam[j];   // (sequential; obs_cam[i] would be a random gather)
                 if (stamp[c] != tid) {
                   stamp[c] = tid;
                   slot_of[c] = T.ncs++;

@@ -24,6 +24,12 @@ __global__ void k_sort_keys(int64_t n_obs, const int32_t* __restrict__ obs_cam, 
   val[i] = (uint32_t)i;
 }
 
+// camera of every sorted key (its low 24 bits)
+__global__ void k_key_cam(int64_t n, const uint64_t* __restrict__ key, int32_t* __restrict__ cam) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cam[i] = (int32_t)(key[i] & 0xFFFFFFu);
+}
+
 // measurements in slot order: oxy[chunk][2][256] from the caller's obs_xy through slot_orig; model 1 uploads o - observed
 __global__ void k_gather_oxy(int64_t n_slots, const int64_t* __restrict__ slot_orig, const double2* __restrict__ obs_xy,
                              const int32_t* __restrict__ obs_cam, const double2* __restrict__ principal /*or null*/,
