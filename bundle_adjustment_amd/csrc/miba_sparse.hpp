@@ -14,42 +14,124 @@
 
 namespace miba {
 
-// x L' = a for one row a held in registers (x overwrites it): right-looking forward substitution against the diagonal factor in
-// LDS (Lt[k][c] = L[c][k], Lr = 1 / diagonal), every solved entry updates all the later ones with independent FMAs
-__device__ __forceinline__ void tchol_row_solve(double* x, const double* Lt, const double* Lr) {
-#pragma unroll
-  for (int k = 0; k < kNB; ++k) {
-    const double xk = x[k] * Lr[k];
-    x[k] = xk;
-    double t[kNB];
-#pragma unroll
-    for (int c = k + 1; c < kNB; ++c) t[c] = Lt[k * kLs + c];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = k + 1; c < kNB; ++c) x[c] = fma(-xk, t[c], x[c]);
-#pragma unroll
-    for (int c = k + 1; c < kNB; ++c) asm volatile("" : "+v"(x[c]));
-  }
-}
+// 16 x 16 blocks of matrices held in LDS as operands of v_mfma_f64_16x16x4_f64 (lane l: r = l & 15, g = l >> 4):
+// A fragment kk = A[r][4 kk + g], B fragment kk = B[4 kk + g][r], D register reg = D[g + 4 reg][r].
 
-// Column step k, first launch (one wave): Cholesky factor L of the diagonal tile (chol_diag_wave, miba_dense.hpp), then
-// W = L^-T by solving x L' = e_lane against it.  Only W leaves the kernel (Winv[c * 64 + i] = W[i][c]): the panel tiles are
-// multiplied by it on the matrix cores (k_tchol_panel), and the backward substitution uses it too; the factor of the diagonal
-// tile itself is never needed again.  (One sweep for both, sharing the LDS operands, would save a third of the time; the
-// doubly unrolled 64-step nest does not get through the compiler in a quarter of an hour.)
+// Column step k, first launch (one wave): Cholesky factor L of the diagonal tile, then W = L^-T.  Only W leaves the kernel
+// (Winv[c * 64 + i] = W[i][c] = (L^-1)[c][i], i.e. L^-1 row-major): the panel tiles are multiplied by it on the matrix cores
+// (k_tchol_panel), and the backward substitution uses it too; the factor of the diagonal tile itself is never needed again.
+// Both halves are blocked by 16 so that the chain of dependent steps is 4 x 16 + 16 instead of 64 + 64 steps of up to 63
+// FMAs each (one wave issues an fp64 FMA every 8 cycles):
+//   factor   per block column: the 16 columns right-looking with lane = row (chol_diag_wave's step, 15 FMAs at most), then
+//            the trailing blocks A_pq -= L_p L_q' on the matrix cores, operands straight from the factor in LDS;
+//   inverse  M = L^-1: the four diagonal blocks at once (lane = block, column: sixteen substitution steps), then the blocks at
+//            distance 1, 2, 3 from the diagonal, M_ab = -M_aa sum_c L_ac M_cb, two matrix-core stages each.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_diag(const double* __restrict__ tiles, const int32_t* __restrict__ slots /*of this column*/,
                                                    double* __restrict__ Winv /*[64 * 64]*/, int* __restrict__ flag) {
-  __shared__ __align__(16) double Lt[kNB * kLs];
-  __shared__ double Lr[kNB];
-  const int lane = threadIdx.x;
-  const bool bad = chol_diag_wave(tiles + (size_t)slots[0] * 4096, 64, lane, Lt, Lr);
+  __shared__ __align__(16) double As[kNB * kLs];   // the tile, row-major; later M = L^-1, row-major
+  __shared__ __align__(16) double Lt[kNB * kLs];   // Lt[k][r] = L[r][k]
+  __shared__ double Lr[kNB];                       // 1 / L[k][k]
+  __shared__ double Sb[3][256];
+  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+  const double* A = tiles + (size_t)slots[0] * 4096;
+#pragma unroll
+  for (int r0 = 0; r0 < kNB; r0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = A[(size_t)(r0 + i) * kNB + lane];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) As[(r0 + i) * kLs + lane] = v[i];
+  }
+  bool bad = false;
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = As[lane * kLs + 16 * jb + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int J = 16 * jb + j;
+      double d = lane_bcast(a[j], J);
+      if (!(d > 0.0)) { bad = true; d = 1.0; }
+      const double rd = mf_rsqrt(d);
+      const double l = (lane >= J) ? a[j] * rd : 0.0;
+      Lt[J * kLs + lane] = l;
+      if (lane == 0) Lr[J] = rd;
+      double t[16];   // (requested together: taken one by one, each read costs its LDS round trip)
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) t[c] = Lt[J * kLs + 16 * jb + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) a[c] = fma(-l, t[c], a[c]);
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) asm volatile("" : "+v"(a[c]));
+    }
+    // trailing blocks (p, q), jb < q <= p: A_pq -= L_p,jb L_q,jb'   (the accumulator starts at -A_pq and is stored negated)
+#pragma unroll
+    for (int p = jb + 1; p < 4; ++p)
+#pragma unroll
+      for (int q = jb + 1; q <= p; ++q) {
+        d4_t c;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) c[reg] = -As[(16 * p + g + 4 * reg) * kLs + 16 * q + r];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[(16 * jb + 4 * kk + g) * kLs + 16 * p + r], Lt[(16 * jb + 4 * kk + g) * kLs + 16 * q + r], c, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) As[(16 * p + g + 4 * reg) * kLs + 16 * q + r] = -c[reg];
+      }
+  }
   if (bad && lane == 0) *flag = 1;
-  double x[kNB];
+  // M_aa = L_aa^-1, a = g: lane (g, r) solves x L_aa' = e_r, which is column r of M_aa
+  {
+    double x[16];
 #pragma unroll
-  for (int c = 0; c < kNB; ++c) x[c] = (c == lane) ? 1.0 : 0.0;
-  tchol_row_solve(x, Lt, Lr);
+    for (int c = 0; c < 16; ++c) x[c] = (c == r) ? 1.0 : 0.0;
 #pragma unroll
-  for (int c = 0; c < kNB; ++c) Winv[c * kNB + lane] = x[c];
+    for (int k = 0; k < 16; ++k) {
+      const double xk = x[k] * Lr[16 * g + k];
+      x[k] = xk;
+      double t[16];
+#pragma unroll
+      for (int c = k + 1; c < 16; ++c) t[c] = Lt[(16 * g + k) * kLs + 16 * g + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = k + 1; c < 16; ++c) x[c] = fma(-xk, t[c], x[c]);
+#pragma unroll
+      for (int c = k + 1; c < 16; ++c) asm volatile("" : "+v"(x[c]));
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) As[(16 * g + c) * kLs + 16 * g + r] = x[c];
+  }
+  // blocks at distance dd below the diagonal: S = sum_{c = b}^{a - 1} L_ac M_cb, then M_ab = -M_aa S
+#pragma unroll
+  for (int dd = 1; dd < 4; ++dd) {
+#pragma unroll
+    for (int a = dd; a < 4; ++a) {
+      const int b = a - dd;
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int cc = b; cc < a; ++cc)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[(16 * cc + 4 * kk + g) * kLs + 16 * a + r], As[(16 * cc + 4 * kk + g) * kLs + 16 * b + r], c, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Sb[a - dd][(g + 4 * reg) * 16 + r] = c[reg];
+    }
+#pragma unroll
+    for (int a = dd; a < 4; ++a) {
+      const int b = a - dd;
+      d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * a + r) * kLs + 16 * a + 4 * kk + g], Sb[a - dd][(4 * kk + g) * 16 + r], c, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) As[(16 * a + g + 4 * reg) * kLs + 16 * b + r] = -c[reg];
+    }
+  }
+  // M is lower block triangular: the blocks above the diagonal still hold what is left of the tile
+#pragma unroll 16
+  for (int c = 0; c < kNB; ++c) Winv[c * kNB + lane] = (g <= (c >> 4)) ? As[c * kLs + lane] : 0.0;
 }
 
 // Column step k, second launch: panel tile b of the column (slots[b]: the tiles below the diagonal, the right-hand-side tile

@@ -1,4 +1,5 @@
-"""Idle time between consecutive kernels of a rocprofv3 --kernel-trace run (rocpd database): python tools/gap_analysis.py <results.db>
+"""Idle time between consecutive kernels of a rocprofv3 --kernel-trace run (rocpd database):
+python tools/gap_analysis.py <results.db> [first-kernel-prefix last-kernel-prefix]   (default: k_mf_matvec .. pcg_tail, the PCG solve)
 Prints the busy / idle split of the solve and the idle time by (previous kernel -> next kernel) pair."""
 import collections
 import re
@@ -9,8 +10,10 @@ c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select name,start,end from kernels order by start"))
 short = lambda n: re.sub(r"\(.*$", "", n).replace("void ", "").replace("miba::", "")
 names = [short(r[0]) for r in rows]
-first = min(i for i, n in enumerate(names) if n.startswith("k_mf_matvec"))
-last = max(i for i, n in enumerate(names) if n.startswith("pcg_tail") or n.startswith("pcg_update"))
+p_first = sys.argv[2] if len(sys.argv) > 3 else "k_mf_matvec"
+p_last = sys.argv[3] if len(sys.argv) > 3 else "pcg_tail"
+first = min(i for i, n in enumerate(names) if n.startswith(p_first))
+last = max(i for i, n in enumerate(names) if n.startswith(p_last))
 gaps = collections.defaultdict(lambda: [0, 0.0, 0.0])
 busy = 0.0
 for i in range(first, last):
