@@ -197,6 +197,7 @@ struct miba_handle_s {
   int32_t *d_sp_map = nullptr, *d_sp_pos = nullptr, *d_sp_grp = nullptr;
   int32_t *d_sp_col_rows = nullptr, *d_sp_col_slots = nullptr, *d_sp_row_cols = nullptr, *d_sp_row_slots = nullptr;
   std::vector<int64_t> sp_col_ptr, sp_row_ptr;
+  std::vector<int32_t> sp_row_last;   // column of the last tile of every tile row (-1: none)
   double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
   double *d_sum = nullptr, *d_max = nullptr;   // [S_COUNT] each
   Ctl* d_ctl = nullptr;
@@ -1094,9 +1095,11 @@ int sparse_symbolic(miba_handle h) {
   col_ptr[nT] = (int64_t)col_rows.size();
   std::vector<int32_t> row_cols, row_slots;
   std::vector<int64_t> row_ptr(nT + 1, 0);
+  std::vector<int32_t> row_last(nT, -1);
   for (int r = 0; r < nT; ++r) {
     row_ptr[r] = (int64_t)row_cols.size();
     for (auto& e : row_list[r]) { row_cols.push_back(e.first); row_slots.push_back(e.second); }
+    row_last[r] = row_list[r].empty() ? -1 : row_list[r].back().first;
   }
   row_ptr[nT] = (int64_t)row_cols.size();
 
@@ -1124,6 +1127,7 @@ int sparse_symbolic(miba_handle h) {
   if ((rc = upload(h, h->d_sp_row_slots, row_slots.data(), row_slots.size()))) return rc;
   h->sp_col_ptr.swap(col_ptr);
   h->sp_row_ptr.swap(row_ptr);
+  h->sp_row_last.swap(row_last);
   h->sp_nT = nT;
   h->sp_n_mat = n_mat;
   if (!h->dense_plan_tried && (rc = dense_plan(h))) return rc;
@@ -1147,19 +1151,22 @@ int sparse_solve(miba_handle h, int* status) {
     const int64_t c0 = h->sp_col_ptr[k];
     const int cnt = (int)(h->sp_col_ptr[k + 1] - c0);   // diagonal, tiles below it, right-hand side
     double* W = h->d_sp_Ldiag + (size_t)k * 4096;
-    hipLaunchKernelGGL(k_tchol_diag, dim3(1), dim3(kNB), 0, h->st, (const double*)T, (const int32_t*)(h->d_sp_col_slots + c0), W, (int*)h->d_dflag);
     const int m = cnt - 1;   // tiles below the diagonal, the right-hand-side tile among them
-    hipLaunchKernelGGL(k_tchol_panel, dim3(m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const double*)W);
+    hipLaunchKernelGGL(k_tchol_col, dim3(m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_slots + c0), W, (int*)h->d_dflag);
     if (m > 1)
       hipLaunchKernelGGL(k_tchol_update, dim3(m, m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_rows + c0 + 1),
                          (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const int32_t*)h->d_sp_map, nT);
   }
   hipLaunchKernelGGL(k_tchol_gety, dim3(nb64), dim3(256), 0, h->st, nT, (const double*)T, (int)n_mat, h->d_sp_y);
+  int have_x = 0;
   for (int k = nT - 1; k >= 0; --k) {
     const int64_t r0 = h->sp_row_ptr[k];
     const int nr = (int)(h->sp_row_ptr[k + 1] - r0);
+    // the tiles of a row are listed by ascending column: the last one is (k, k - 1) if that tile exists
+    const int ahead = (nr > 0 && h->sp_row_last[k] == k - 1) ? nr - 1 : -1;
     hipLaunchKernelGGL(k_tchol_bwd, dim3(nr > 0 ? nr : 1), dim3(kNB), 0, h->st, (const double*)T, k, nr, (const int32_t*)(h->d_sp_row_cols + r0),
-                       (const int32_t*)(h->d_sp_row_slots + r0), (const double*)(h->d_sp_Ldiag + (size_t)k * 4096), h->d_sp_y, h->d_sp_x);
+                       (const int32_t*)(h->d_sp_row_slots + r0), (const double*)h->d_sp_Ldiag, h->d_sp_y, h->d_sp_x, have_x, ahead);
+    have_x = ahead >= 0;
   }
   hipLaunchKernelGGL(k_tchol_unperm, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, (const double*)h->d_sp_x,
                      (const int32_t*)h->d_sp_pos, h->d_px);

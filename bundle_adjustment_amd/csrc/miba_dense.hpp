@@ -472,14 +472,19 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
   const int tid = threadIdx.x;
   const int base = k0 + kNB;
   const int cj = base + kNB * J;
-  for (int i = tid; i < kNB * kNB; i += 256) bt[i >> 6][i & 63] = S[(size_t)(cj + (i >> 6)) * N + k0 + (i & 63)];
-  __syncthreads();
   const int l = tid & 63, wv = tid >> 6;
   const int ar = l & 15, ak = l >> 4;
   const int ri = base + kNB * I + 16 * wv;
-  double af[16];
+  // both operands requested before the first wait (as a loop "load, store to LDS" the staging took sixteen trips to memory)
+  double bv[16], af[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bv[q] = S[(size_t)(cj + 4 * q + wv) * N + k0 + l];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) af[kk] = S[(size_t)(ri + ar) * N + k0 + 4 * kk + ak];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bt[4 * q + wv][l] = bv[q];
+  __syncthreads();
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     d4_t c = {0.0, 0.0, 0.0, 0.0};
@@ -498,7 +503,14 @@ __global__ __launch_bounds__(256) void k_chol_bwd(double* __restrict__ S, int N,
   __shared__ double xk[kNB];
   const int tid = threadIdx.x;
   double* y = S + (size_t)N * N;
-  for (int i = tid; i < kNB * kNB; i += 256) Ls[(i >> 6) * kLs + (i & 63)] = Ldiag[i];
+  {
+    double lv[16];   // (requested together: as a loop "load, store to LDS" this took sixteen trips to memory)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lv[q] = Ldiag[tid + 256 * q];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Ls[(4 * q + (tid >> 6)) * kLs + (tid & 63)] = lv[q];
+  }
   __syncthreads();
   if (tid < kNB) {
     double yv = y[k0 + tid];

@@ -17,23 +17,18 @@ namespace miba {
 // 16 x 16 blocks of matrices held in LDS as operands of v_mfma_f64_16x16x4_f64 (lane l: r = l & 15, g = l >> 4):
 // A fragment kk = A[r][4 kk + g], B fragment kk = B[4 kk + g][r], D register reg = D[g + 4 reg][r].
 
-// Column step k, first launch (one wave): Cholesky factor L of the diagonal tile, then W = L^-T.  Only W leaves the kernel
-// (Winv[c * 64 + i] = W[i][c] = (L^-1)[c][i], i.e. L^-1 row-major): the panel tiles are multiplied by it on the matrix cores
-// (k_tchol_panel), and the backward substitution uses it too; the factor of the diagonal tile itself is never needed again.
+// One wave: Cholesky factor L of a diagonal tile, then W = L^-T, both left in LDS.  Only W is ever used (Winv[c * 64 + i] =
+// W[i][c] = (L^-1)[c][i], i.e. L^-1 row-major): the tiles of the column are multiplied by it on the matrix cores (k_tchol_col),
+// and the backward substitution uses it too; the factor of the diagonal tile itself is never needed again.
 // Both halves are blocked by 16 so that the chain of dependent steps is 4 x 16 + 16 instead of 64 + 64 steps of up to 63
 // FMAs each (one wave issues an fp64 FMA every 8 cycles):
 //   factor   per block column: the 16 columns right-looking with lane = row (chol_diag_wave's step, 15 FMAs at most), then
 //            the trailing blocks A_pq -= L_p L_q' on the matrix cores, operands straight from the factor in LDS;
 //   inverse  M = L^-1: the four diagonal blocks at once (lane = block, column: sixteen substitution steps), then the blocks at
 //            distance 1, 2, 3 from the diagonal, M_ab = -M_aa sum_c L_ac M_cb, two matrix-core stages each.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_diag(const double* __restrict__ tiles, const int32_t* __restrict__ slots /*of this column*/,
-                                                   double* __restrict__ Winv /*[64 * 64]*/, int* __restrict__ flag) {
-  __shared__ __align__(16) double As[kNB * kLs];   // the tile, row-major; later M = L^-1, row-major
-  __shared__ __align__(16) double Lt[kNB * kLs];   // Lt[k][r] = L[r][k]
-  __shared__ double Lr[kNB];                       // 1 / L[k][k]
-  __shared__ double Sb[3][256];
-  const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-  const double* A = tiles + (size_t)slots[0] * 4096;
+__device__ __forceinline__ bool tchol_diag_wave(const double* __restrict__ A, const int lane, double* As /*[64][kLs]: the tile, then M = L^-1, row-major*/,
+                                                double* Lt /*[64][kLs]: Lt[k][r] = L[r][k]*/, double* Lr /*[64]: 1 / L[k][k]*/, double (*Sb)[256]) {
+  const int r = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int r0 = 0; r0 < kNB; r0 += 16) {
     double v[16];
@@ -81,7 +76,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int reg = 0; reg < 4; ++reg) As[(16 * p + g + 4 * reg) * kLs + 16 * q + r] = -c[reg];
       }
   }
-  if (bad && lane == 0) *flag = 1;
   // M_aa = L_aa^-1, a = g: lane (g, r) solves x L_aa' = e_r, which is column r of M_aa
   {
     double x[16];
@@ -129,42 +123,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       for (int reg = 0; reg < 4; ++reg) As[(16 * a + g + 4 * reg) * kLs + 16 * b + r] = -c[reg];
     }
   }
-  // M is lower block triangular: the blocks above the diagonal still hold what is left of the tile
-#pragma unroll 16
-  for (int c = 0; c < kNB; ++c) Winv[c * kNB + lane] = (g <= (c >> 4)) ? As[c * kLs + lane] : 0.0;
+  return bad;   // (M is lower block triangular: the blocks of As above the diagonal still hold what is left of the tile)
 }
 
-// Column step k, second launch: panel tile b of the column (slots[b]: the tiles below the diagonal, the right-hand-side tile
-// last) becomes X = A W = A L^-T on the fp64 matrix cores: wave = 16 rows, A fragment lane l = A[l & 15][4 kk + (l >> 4)],
-// B[k][n] = W[k][16 nt + n] = Winv[(16 nt + n) * 64 + k], D: row (l >> 4) + 4 reg, column l & 15.  In place: a wave reads all
-// of its sixteen rows before it writes any of them, and nobody else touches them.
-__global__ __launch_bounds__(256) void k_tchol_panel(double* __restrict__ tiles, const int32_t* __restrict__ slots, const double* __restrict__ Winv) {
-  __shared__ double wt[kNB][kNB + 1];
+// Column step k, first launch: workgroup b turns tile b of the column (slots[1 + b]: the tiles below the diagonal, the
+// right-hand-side tile last) into X = A W = A L^-T.  Every workgroup factors and inverts the diagonal tile (slots[0]) itself,
+// on its first wave, while the loads of its own tile are in flight: a launch that does it once and hands W over through memory
+// costs the column another launch ramp and two trips to memory (9 us where the product itself is 1.5).  Workgroup 0 leaves W
+// for the backward substitution.  Product on the fp64 matrix cores: wave = 16 rows, A fragment lane l = A[l & 15][4 kk + (l >> 4)],
+// B[k][n] = W[k][16 nt + n] = M[16 nt + n][k] (zero for k >= 16 (nt + 1): M is lower block triangular), D: row (l >> 4) + 4 reg,
+// column l & 15.  In place: a wave reads all of its sixteen rows before it writes any of them, and nobody else touches them.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_col(double* __restrict__ tiles, const int32_t* __restrict__ slots /*of this column*/,
+                                                   double* __restrict__ Winv /*[64 * 64]*/, int* __restrict__ flag) {
+  __shared__ __align__(16) double As[kNB * kLs];
+  __shared__ __align__(16) double Lt[kNB * kLs];
+  __shared__ double Lr[kNB];
+  __shared__ double Sb[3][256];
   const int tid = threadIdx.x;
-  double* A = tiles + (size_t)slots[blockIdx.x] * 4096;
-  for (int i = tid; i < kNB * kNB; i += 256) wt[i >> 6][i & 63] = Winv[i];
   const int l = tid & 63, wv = tid >> 6;
   const int ar = l & 15, ak = l >> 4;
+  double* A = tiles + (size_t)slots[1 + blockIdx.x] * 4096;
   double af[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
+  if (wv == 0) {
+    const bool bad = tchol_diag_wave(tiles + (size_t)slots[0] * 4096, l, As, Lt, Lr, Sb);
+    if (blockIdx.x == 0) {
+      if (bad && l == 0) *flag = 1;
+#pragma unroll 16
+      for (int c = 0; c < kNB; ++c) Winv[c * kNB + l] = (ak <= (c >> 4)) ? As[c * kLs + l] : 0.0;
+    }
+  }
   __syncthreads();
   d4_t c[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     c[nt] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) c[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], wt[16 * nt + ar][4 * kk + ak], c[nt], 0, 0, 0);
+    for (int kk = 0; kk < 4 * (nt + 1); ++kk) c[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], As[(16 * nt + ar) * kLs + 4 * kk + ak], c[nt], 0, 0, 0);
   }
-  // (the wave's rows are all in af and c by now: the stores below cannot reach a value another lane of the wave still needs,
-  // MFMA operands are read when the instruction issues)
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) A[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] = c[nt][reg];
 }
 
-// trailing update of column step k: tile (r_I, r_J) -= L(r_I, k) L(r_J, k)' for the tiles I >= J below the diagonal of the
+// Column step k, second launch, trailing update: tile (r_I, r_J) -= L(r_I, k) L(r_J, k)' for the tiles I >= J below the diagonal of the
 // column (rows[] / slots[] list them, diagonal excluded); the destination comes from the tile map (symbolic fill guarantees it)
 __global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles, const int32_t* __restrict__ rows,
                                                       const int32_t* __restrict__ slots, const int32_t* __restrict__ map, int nT) {
@@ -179,19 +183,25 @@ __global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles
   const double* B = tiles + (size_t)slots[J] * 4096;
   double* Dt = tiles + (size_t)dslot * 4096;
   const int tid = threadIdx.x;
-  for (int i = tid; i < kNB * kNB; i += 256) bt[i >> 6][i & 63] = B[i];
-  __syncthreads();
   const int l = tid & 63, wv = tid >> 6;
   const int ar = l & 15, ak = l >> 4;
-  double af[16];
+  // both operands and the destination are requested together, before the first wait: one trip to memory.  (As a loop
+  // "load, store to LDS" the staging of B took sixteen trips, one per element and thread.)  The destination is negated as
+  // the accumulator's start.
+  double bv[16], af[16];
+  d4_t c[4];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bv[q] = B[tid + 256 * q];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
-  // the destination is requested together with the operands (one trip to memory, not two), negated as the accumulator's start
-  d4_t c[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) c[nt][reg] = -Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) bt[4 * q + wv][l] = bv[q];   // element tid + 256 q = row 4 q + wv, column l
+  __syncthreads();
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -231,28 +241,68 @@ __global__ void k_tchol_unperm(int n_cam, const double* __restrict__ xp, const i
   x[i] = xp[(size_t)pos[g] * 64 + 9 * (cam - kTileCams * g) + (i - 9 * cam)];
 }
 
-// backward step k of L' x = y: x_k = W_k y_k (every workgroup, one wave; W_k = L_kk^-T from the panel step), then workgroup b takes
-// tile (k, J_b) of tile row k: y_J -= L(k, J)' x_k
-__global__ __launch_bounds__(64) void k_tchol_bwd(const double* __restrict__ tiles, int k, int n_row_tiles, const int32_t* __restrict__ cols,
-                                                  const int32_t* __restrict__ slots, const double* __restrict__ Winv, double* __restrict__ y,
-                                                  double* __restrict__ x) {
+// backward step k of L' x = y.  x_k = W_k y_k (W_k = L_kk^-T from the column's first launch) comes from the launch before
+// this one when have_x is set, else every workgroup (one wave) forms it; then workgroup b takes tile (k, J_b) of tile row k:
+// y_J -= L(k, J)' x_k.  Workgroup `ahead` (or -1) holds the tile with J = k - 1: after its update y_(k-1) is final (the rows
+// above k were applied by earlier launches), so it goes on to x_(k-1) = W_(k-1) y_(k-1) with W requested at the start, and
+// the next launch finds it in memory instead of waiting for W and y itself.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_bwd(const double* __restrict__ tiles, int k, int n_row_tiles, const int32_t* __restrict__ cols,
+                                                  const int32_t* __restrict__ slots, const double* __restrict__ Winv_all, double* __restrict__ y,
+                                                  double* __restrict__ x, int have_x, int ahead) {
   __shared__ double ys[kNB];
   __shared__ double xk[kNB];
   const int tid = threadIdx.x;
-  ys[tid] = y[k * kNB + tid];
+  const bool lead = (int)blockIdx.x == ahead;
+  const bool work = (int)blockIdx.x < n_row_tiles;
+  // everything the step reads is requested before the first wait: the tile (one column per lane), the entry of y it updates,
+  // W of the next step in the workgroup that runs ahead.  (Left to the compiler the tile's loads came one by one, each
+  // waited for before the next: the 64 FMAs form one chain, and it saw no reason to keep registers for loads in flight.)
+  const double* T = tiles + (size_t)(work ? slots[blockIdx.x] : 0) * 4096;   // (a row without tiles has no list to read)
+  const int col = work ? cols[blockIdx.x] : 0;
+  double tv[kNB], wn[kNB];
+  double y_old = 0.0;
+  if (work) {
+#pragma unroll
+    for (int r = 0; r < kNB; ++r) tv[r] = T[(size_t)r * 64 + tid];
+    y_old = y[col * kNB + tid];
+  }
+  if (lead) {
+    const double* Wn = Winv_all + (size_t)(k - 1) * 4096;
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) wn[c] = Wn[c * kNB + tid];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (have_x) {
+    xk[tid] = x[k * kNB + tid];
+  } else {
+    const double* Wk = Winv_all + (size_t)k * 4096;
+    ys[tid] = y[k * kNB + tid];
+    double wk[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) wk[c] = Wk[c * kNB + tid];
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    double xv = 0.0;
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) xv = fma(wk[c], ys[c], xv);
+    xk[tid] = xv;
+    if (blockIdx.x == 0) x[k * kNB + tid] = xv;
+  }
   __syncthreads();
-  double xv = 0.0;
-#pragma unroll 16
-  for (int c = 0; c < kNB; ++c) xv = fma(Winv[c * kNB + tid], ys[c], xv);
-  xk[tid] = xv;
-  if (blockIdx.x == 0) x[k * kNB + tid] = xv;
-  __syncthreads();
-  if ((int)blockIdx.x >= n_row_tiles) return;
-  const double* T = tiles + (size_t)slots[blockIdx.x] * 4096;
+  if (!work) return;
   double sacc = 0.0;
-#pragma unroll 16
-  for (int r = 0; r < kNB; ++r) sacc = fma(T[(size_t)r * 64 + tid], xk[r], sacc);
-  y[cols[blockIdx.x] * kNB + tid] -= sacc;
+#pragma unroll
+  for (int r = 0; r < kNB; ++r) sacc = fma(tv[r], xk[r], sacc);
+  const double yn = y_old - sacc;
+  y[col * kNB + tid] = yn;
+  if (lead) {
+    ys[tid] = yn;
+    __syncthreads();
+    double xv = 0.0;
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) xv = fma(wn[c], ys[c], xv);
+    x[(k - 1) * kNB + tid] = xv;
+  }
 }
 
 }  // namespace miba
