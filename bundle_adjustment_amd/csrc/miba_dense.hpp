@@ -32,17 +32,34 @@ struct SDst {
   const int32_t* pos;
   int nT;
 };
-__device__ __forceinline__ double* sdst_addr(const SDst D, int ci, int a, int cj, int b) {
-  if (!D.map) return D.S + (size_t)(9 * ci + a) * D.N + (9 * cj + b);
-  const int gi = ci / kTileCams, gj = cj / kTileCams;
-  int tr = D.pos[gi], tc = D.pos[gj];
-  int lr = 9 * (ci - kTileCams * gi) + a, lc = 9 * (cj - kTileCams * gj) + b;
-  if (tr < tc || (tr == tc && lr < lc)) {
-    if (ci == cj) return nullptr;
-    int t = tr; tr = tc; tc = t;
-    t = lr; lr = lc; lc = t;
+// The camera block (ci, cj) is located once (the tile lookups are two dependent trips to memory), its entries by arithmetic.
+struct SBlock {
+  double* p;    // kind 0: entry (a, b) at p[a * ld + b]; kind 1: transposed, p[b * ld + a]; kind 2: p is a diagonal tile
+  int ld, kind;
+  int lr0, lc0; // kind 2: the block's first row and column inside the tile
+};
+__device__ __forceinline__ SBlock sdst_block(const SDst D, int ci, int cj) {
+  SBlock B;
+  if (!D.map) {
+    B.p = D.S + (size_t)(9 * ci) * D.N + 9 * cj; B.ld = D.N; B.kind = 0; B.lr0 = 0; B.lc0 = 0;
+    return B;
   }
-  return D.S + (size_t)D.map[(size_t)tr * D.nT + tc] * 4096 + (size_t)lr * 64 + lc;
+  const int gi = ci / kTileCams, gj = cj / kTileCams;
+  const int tr = D.pos[gi], tc = D.pos[gj];
+  B.lr0 = 9 * (ci - kTileCams * gi); B.lc0 = 9 * (cj - kTileCams * gj);
+  B.ld = 64;
+  if (tr > tc) { B.kind = 0; B.p = D.S + (size_t)D.map[(size_t)tr * D.nT + tc] * 4096 + (size_t)B.lr0 * 64 + B.lc0; }
+  else if (tr < tc) { B.kind = 1; B.p = D.S + (size_t)D.map[(size_t)tc * D.nT + tr] * 4096 + (size_t)B.lc0 * 64 + B.lr0; }
+  else { B.kind = 2; B.p = D.S + (size_t)D.map[(size_t)tr * D.nT + tr] * 4096; }
+  return B;
+}
+// same_cam: the block is a camera's own diagonal block, whose entries above the diagonal are dropped
+__device__ __forceinline__ double* sdst_entry(const SBlock& B, bool same_cam, int a, int b) {
+  if (B.kind == 0) return B.p + (size_t)a * B.ld + b;
+  if (B.kind == 1) return B.p + (size_t)b * B.ld + a;
+  const int lr = B.lr0 + a, lc = B.lc0 + b;
+  if (lr >= lc) return B.p + lr * 64 + lc;
+  return same_cam ? nullptr : B.p + lc * 64 + lr;
 }
 
 // G = E' F_s (3x9, row a = point coordinate) of one observation and T = W G
@@ -69,12 +86,13 @@ __device__ __forceinline__ void dense_WG(const double* W /*00 10 11 20 21 22*/, 
 
 // S[cam_i block row][cam_j block column] -= T_i' G_j
 __device__ __forceinline__ void dense_sub_block(const SDst D, int cam_i, int cam_j, const double* T, const double* Gj) {
+  const SBlock B = sdst_block(D, cam_i, cam_j);
 #pragma unroll
   for (int a = 0; a < 9; ++a)
 #pragma unroll
     for (int b = 0; b < 9; ++b) {
       const double v = -(T[a] * Gj[b] + T[9 + a] * Gj[9 + b] + T[18 + a] * Gj[18 + b]);
-      double* dst = sdst_addr(D, cam_i, a, cam_j, b);
+      double* dst = sdst_entry(B, cam_i == cam_j, a, b);
       if (dst) atomicAdd(dst, v);
     }
 }
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __r
   const int first = __builtin_amdgcn_readfirstlane(Sg.y), n = __builtin_amdgcn_readfirstlane(Sg.z);
   const int w4 = __builtin_amdgcn_readfirstlane(Sg.w);
   const int use_atomic = w4 >> 30, cj = w4 & 0x3FFFFFFF;
+  const SBlock B = sdst_block(D, ci, cj);   // (wave-uniform, requested here: the lookups are back long before the stores)
   double cdi[kCamLds], cdj[kCamLds], sci[9], scj[9];
   mf_stage_cam_init(cdi, ci, ct, cm);
   mf_stage_cam_init(cdj, cj, ct, cm);
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __r
 #pragma unroll
     for (int s2 = 1; s2 < 7; ++s2) tot += __shfl(a, k9 + 9 * s2, 64);
     if (lane < 9) {
-      double* dst = sdst_addr(D, ci, r, cj, lane);
+      double* dst = sdst_entry(B, ci == cj, r, lane);
       if (dst) {
         if (use_atomic) atomicAdd(dst, -tot);
         else *dst = -tot;
@@ -364,7 +383,8 @@ __global__ void k_dense_diag(int n_cam, const double* __restrict__ acc /*[n][64]
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     double v = acc[(size_t)kK2W * c + (9 * lo - (lo * (lo - 1)) / 2 + (hi - lo))];
     if (a == b) v += Dc2[9 * (size_t)c + a];
-    double* dst = sdst_addr(D, c, a, c, b);
+    const SBlock B = sdst_block(D, c, c);
+    double* dst = sdst_entry(B, true, a, b);
     if (dst) *dst += v;
   }
   const size_t r = 9 * (size_t)n_cam + i;
