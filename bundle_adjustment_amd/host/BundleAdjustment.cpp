@@ -291,8 +291,8 @@ void BundleAdjustment::solve() {
                                         ? "ITERATIVE_SCHUR (HIP implicit-Schur PCG, SCHUR_JACOBI preconditioner)"
                                         : "ITERATIVE_SCHUR (HIP implicit-Schur PCG, JACOBI preconditioner)")
                                  : ms.exact_linear_solver
-                                       ? "DENSE_SCHUR / SPARSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device: dense up to "
-                                         "2048 cameras, 64 x 64 tiles of the sparse Schur complement beyond)"
+                                       ? "DENSE_SCHUR / SPARSE_SCHUR (HIP explicit Schur complement + blocked Cholesky on the device over 64 x 64 "
+                                         "tiles of the sparse Schur complement; dense up to 2048 cameras where the tiles are not available)"
                                        : "ITERATIVE_SCHUR (HIP implicit-Schur PCG run to q-tolerance 1e-12 in place of the exact solver: "
                                          "the tiles of the Schur complement do not fit the free device memory, or MIBA_DENSE=0)";
 

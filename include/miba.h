@@ -113,7 +113,7 @@ enum { MIBA_PRECOND_JACOBI = 0, MIBA_PRECOND_SCHUR_JACOBI = 1 };
 typedef struct {
   int32_t max_num_iterations;               /* app/main.cpp:27 -> 80; Ceres default 50 */
   int32_t linear_solver_type;               /* MIBA_* above; all but ITERATIVE_SCHUR are solved exactly on the device
-                                               (<= 2048 cameras) or as tight-tolerance PCG (eta_exact), and reported so */
+                                               (tiles of the Schur complement) or as tight-tolerance PCG (eta_exact), and reported so */
   int32_t jacobi_scaling;                   /* 1 */
   int32_t max_linear_solver_iterations;     /* 500 */
   int32_t min_linear_solver_iterations;     /* 0 */

@@ -62,6 +62,19 @@ def test_cholesky_reports_indefinite_matrix():
     assert st == 2
 
 
+@pytest.fixture(autouse=True)
+def dense_path():
+    """The tiles (tests/test_gpu_sparse.py) are the default exact solver at every size; this file keeps the dense
+    factorisation, their fallback, covered."""
+    old = os.environ.get("MIBA_EXACT")
+    os.environ["MIBA_EXACT"] = "dense"
+    yield
+    if old is None:
+        os.environ.pop("MIBA_EXACT", None)
+    else:
+        os.environ["MIBA_EXACT"] = old
+
+
 @pytest.fixture(params=["planned", "atomics"])
 def assembly(request):
     """Both assembly kernels: the host-planned, atomic-free k_dense_blocks (default) and k_dense_pairs /
