@@ -806,13 +806,133 @@ int exact_kind(miba_handle h, const miba_options* o, int* kind) {
 
 // Pair plan of the explicit Schur complement: every (observation a, observation b) of one point with
 // camera(a) > camera(b), or the same camera (both orders and a == b: duplicates square correctly), is one
-// instance of block (camera(a), camera(b)); instances are counting-sorted by block and cut into segments.
-// Skipped (k_dense_pairs' atomics take over) beyond kDensePlanMax instances or with MIBA_DENSE_PLAN=0.
+// instance of block (camera(a), camera(b)); instances are sorted by block (ascending points inside a block) and cut into
+// segments.  Built on the device (dense_plan_device: a radix sort of the instances, up to 2^30 of them, any number of
+// cameras); on the host threads' counting sort where that does not apply (a point that sees a camera twice, no memory for
+// the sort) up to 20,000 cameras and 2^28 instances.  Skipped (k_dense_pairs' atomics take over) beyond that or with
+// MIBA_DENSE_PLAN=0; MIBA_DENSE_PLAN=host keeps the host plan (the reference for the test of the device plan).
 constexpr int64_t kDensePlanMax = (int64_t)1 << 28;
-int dense_plan(miba_handle h) {
+constexpr int64_t kDensePlanMaxDevice = (int64_t)1 << 30;
+
+static void dense_plan_segments(const std::vector<uint32_t>& bstart, const std::vector<uint64_t>& bkey, int64_t total, std::vector<int4>& segs) {
+  const size_t nb = bstart.size();
+  segs.reserve(nb + (size_t)(total / kDenseSeg));
+  for (size_t k = 0; k < nb; ++k) {
+    const int64_t f = bstart[k], n = (k + 1 < nb ? (int64_t)bstart[k + 1] : total) - f;
+    const int ci = (int)(bkey[k] >> 24), cj = (int)(bkey[k] & 0xFFFFFFu);
+    for (int64_t o = 0; o < n; o += kDenseSeg)
+      segs.push_back(make_int4(ci, (int)(f + o), (int)std::min<int64_t>(kDenseSeg, n - o), cj | ((n > kDenseSeg ? 1 : 0) << 30)));
+  }
+}
+
+// *done = true: d_dseg / d_dpts hold the plan.  *done = false with MIBA_OK: not applicable, the caller tries the host plan.
+static int dense_plan_device(miba_handle h, bool* done) {
+  *done = false;
+  const Plan& P = h->plan_ref();
+  const size_t np = (size_t)h->n_pt;
+  if (np == 0 || h->n_slots == 0) return MIBA_OK;
+  int64_t total = 0;
+  std::vector<int32_t> long_pts;
+  for (size_t q = 0; q < np; ++q) {
+    const int64_t L = P.pt_count[h->pt_base + q];
+    total += L * (L + 1) / 2;
+    if (L > 64) long_pts.push_back((int32_t)q);
+  }
+  if (total <= 0 || total > kDensePlanMaxDevice) return MIBA_OK;
+  const size_t n = (size_t)total;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+  if ((double)n * 40.0 + (double)np * 16.0 > 0.5 * (double)free_b) return MIBA_OK;   // keys twice, values twice, sort scratch
+  uint64_t *cnt = nullptr, *off = nullptr, *k0 = nullptr, *k1 = nullptr, *bkey = nullptr;
+  uint32_t *v0 = nullptr, *pts = nullptr;
+  int32_t *dup = nullptr, *d_long = nullptr;
+  auto cleanup = [&]() {
+    (void)hipFree(cnt); (void)hipFree(off); (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(bkey); (void)hipFree(v0); (void)hipFree(dup);
+    (void)hipFree(d_long); (void)hipFree(pts);
+  };
+  hipError_t e = hipMalloc(&cnt, np * 8);
+  if (e == hipSuccess) e = hipMalloc(&off, np * 8);
+  if (e == hipSuccess) e = hipMalloc(&k0, n * 8);
+  if (e == hipSuccess) e = hipMalloc(&k1, n * 8);
+  if (e == hipSuccess) e = hipMalloc(&v0, n * 4);
+  if (e == hipSuccess) e = hipMalloc(&pts, n * 4);
+  if (e == hipSuccess) e = hipMalloc(&dup, sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&d_long, (long_pts.size() + 1) * sizeof(int32_t));
+  if (e != hipSuccess) { (void)hipGetLastError(); cleanup(); return MIBA_OK; }
+  int32_t h_dup = 0;
+  e = hipMemsetAsync(dup, 0, sizeof(int32_t), h->st);
+  if (e == hipSuccess && !long_pts.empty()) e = hipMemcpyAsync(d_long, long_pts.data(), long_pts.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_inst_count, dim3(nblk(np, 256)), dim3(256), 0, h->st, (int32_t)np, (const int2*)h->d_pt_rng, (const int32_t*)h->d_ocam, cnt, dup);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = device_exclusive_scan(cnt, off, np, h->st);
+  if (e == hipSuccess) e = hipMemcpy(&h_dup, dup, sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && h_dup) { cleanup(); return MIBA_OK; }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_inst_fill, dim3(nblk(np, 256)), dim3(256), 0, h->st, (int32_t)np, (const int2*)h->d_pt_rng, (const int32_t*)h->d_ocam,
+                       (const uint64_t*)off, k0, v0);
+    if (!long_pts.empty())
+      hipLaunchKernelGGL(k_inst_fill_long, dim3((unsigned)long_pts.size()), dim3(256), 0, h->st, (const int32_t*)d_long, (const int2*)h->d_pt_rng,
+                         (const int32_t*)h->d_ocam, (const uint64_t*)off, k0, v0);
+    e = hipGetLastError();
+  }
+  int end_bit = 25;
+  while (end_bit < 48 && ((int64_t)1 << (end_bit - 24)) < (int64_t)h->n_cam) ++end_bit;
+  if (e == hipSuccess) e = device_sort_pairs(k0, k1, v0, pts, n, end_bit, h->st);
+  // block starts: flags and their ranks live in the first key buffer, which the sort has left free
+  uint32_t* flag = (uint32_t*)k0;
+  uint32_t* rank = flag + n;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_inst_heads, dim3(nblk(n, 256)), dim3(256), 0, h->st, (int64_t)n, (const uint64_t*)k1, flag);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = device_exclusive_scan(flag, rank, n, h->st);
+  uint32_t last[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(&last[0], rank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&last[1], flag + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost);
+  const size_t nb = (size_t)last[0] + last[1];
+  std::vector<uint32_t> bstart(nb);
+  std::vector<uint64_t> bkeys(nb);
+  if (e == hipSuccess) e = hipMalloc(&bkey, (nb ? nb : 1) * 8);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_inst_blocks, dim3(nblk(n, 256)), dim3(256), 0, h->st, (int64_t)n, (const uint64_t*)k1, (const uint32_t*)flag, (const uint32_t*)rank,
+                       v0, bkey);   // (the unsorted values are not needed any more: v0 takes the block starts)
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+  if (e == hipSuccess && nb) e = hipMemcpy(bstart.data(), v0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && nb) e = hipMemcpy(bkeys.data(), bkey, nb * 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    return fail(h, MIBA_ERR_HIP, "assembly plan on the device failed: %s", hipGetErrorString(e));
+  }
+  std::vector<int4> segs;
+  dense_plan_segments(bstart, bkeys, total, segs);
+  h->allocs.push_back(pts);   // the sorted points stay: they are the plan
+  h->d_dpts = (int32_t*)pts;
+  pts = nullptr;
+  cleanup();
+  int rc = dev_alloc(h, &h->d_dseg, segs.size());
+  if (rc) return rc;
+  if (!segs.empty()) HIPCHK(h, hipMemcpy(h->d_dseg, segs.data(), segs.size() * sizeof(int4), hipMemcpyHostToDevice));
+  h->n_dseg = (int32_t)segs.size();
+  h->dense_planned = true;
+  *done = true;
+  return MIBA_OK;
+}
+
+static int dense_plan_impl(miba_handle h) {
   h->dense_planned = false;
   h->dense_plan_tried = true;
-  if (const char* e = getenv("MIBA_DENSE_PLAN")) if (atoi(e) == 0) return MIBA_OK;
+  const char* pe = getenv("MIBA_DENSE_PLAN");
+  if (pe && pe[0] == '0') return MIBA_OK;
+  if (!(pe && !strcmp(pe, "host"))) {
+    bool done = false;
+    const int rc = dense_plan_device(h, &done);
+    if (rc || done) return rc;
+  }
   const Plan& P = h->plan_ref();
   const int32_t nc = h->n_cam;
   if (nc > 20000) return MIBA_OK;   // the block directory below is dense in camera pairs: 1.6 GB of host memory at this bound
@@ -862,6 +982,15 @@ int dense_plan(miba_handle h) {
   h->n_dseg = (int32_t)segs.size();
   h->dense_planned = true;
   return MIBA_OK;
+}
+
+int dense_plan(miba_handle h) {
+  const int rc = dense_plan_impl(h);
+  // Ranks of one process that share a device (tests): the plan frees its scratch, and hipFree waits for everything the device
+  // is running, a faster rank's all-reduce kernel included, which in turn waits for this rank.  Nobody goes on to the assembly
+  // before every rank is done here.  (One rank per device, the production layout, has nothing to wait for.)
+  if (!rc && h->grp && h->grp->n > 1 && h->grp->barrier()) return fail(h, MIBA_ERR_RCCL, "a rank of the group left the assembly plan (see its error)");
+  return rc;
 }
 
 int ensure_dense(miba_handle h) {

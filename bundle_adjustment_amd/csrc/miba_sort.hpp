@@ -91,4 +91,69 @@ inline hipError_t device_sort_pairs(uint64_t* key_in, uint64_t* key_out, uint32_
   return e != hipSuccess ? e : e2;
 }
 
+// ---- instance list of the atomic-free assembly of the Schur complement (k_dense_blocks, miba_dense.hpp) on the device ----
+// Every pair of observations (a, b) of one point with camera(a) >= camera(b) is one instance of camera block
+// (camera(a), camera(b)).  The instances are written out point by point as key = camera(a) << 24 | camera(b), value = point,
+// and sorted by key (stable: ascending points inside a block, the order the host plan produces).
+
+// instances per point (a point's slots hold ascending cameras); *dup is set if a point sees one camera twice (the plan then
+// falls back to the host's, which counts such pairs from both sides)
+__global__ void k_inst_count(int32_t n_pt, const int2* __restrict__ pt_rng, const int32_t* __restrict__ ocam, uint64_t* __restrict__ cnt,
+                             int32_t* __restrict__ dup) {
+  const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_pt) return;
+  const int2 r = pt_rng[q];
+  bool d = false;
+  for (int32_t a = 1; a < r.y; ++a) d |= ocam[r.x + a] <= ocam[r.x + a - 1];
+  if (d) *dup = 1;
+  cnt[q] = (uint64_t)r.y * (uint64_t)(r.y + 1) / 2;
+}
+// points of up to 64 observations: one thread writes all pairs of its point
+__global__ void k_inst_fill(int32_t n_pt, const int2* __restrict__ pt_rng, const int32_t* __restrict__ ocam, const uint64_t* __restrict__ off,
+                            uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_pt) return;
+  const int2 r = pt_rng[q];
+  if (r.y > 64) return;
+  uint64_t o = off[q];
+  for (int32_t a = 0; a < r.y; ++a) {
+    const uint64_t ca = (uint64_t)(uint32_t)ocam[r.x + a] << 24;
+    for (int32_t b = 0; b <= a; ++b, ++o) { key[o] = ca | (uint64_t)(uint32_t)ocam[r.x + b]; val[o] = (uint32_t)q; }
+  }
+}
+// longer tracks: one workgroup per point, a thread per observation a
+__global__ void k_inst_fill_long(const int32_t* __restrict__ long_pts, const int2* __restrict__ pt_rng, const int32_t* __restrict__ ocam,
+                                 const uint64_t* __restrict__ off, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const int32_t q = long_pts[blockIdx.x];
+  const int2 r = pt_rng[q];
+  for (int32_t a = threadIdx.x; a < r.y; a += blockDim.x) {
+    uint64_t o = off[q] + (uint64_t)a * (uint64_t)(a + 1) / 2;
+    const uint64_t ca = (uint64_t)(uint32_t)ocam[r.x + a] << 24;
+    for (int32_t b = 0; b <= a; ++b, ++o) { key[o] = ca | (uint64_t)(uint32_t)ocam[r.x + b]; val[o] = (uint32_t)q; }
+  }
+}
+// first instance of every block of the sorted list
+__global__ void k_inst_heads(int64_t n, const uint64_t* __restrict__ key, uint32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+}
+__global__ void k_inst_blocks(int64_t n, const uint64_t* __restrict__ key, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank,
+                              uint32_t* __restrict__ bstart, uint64_t* __restrict__ bkey) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) { bstart[rank[i]] = (uint32_t)i; bkey[rank[i]] = key[i]; }
+}
+template <typename T>
+inline hipError_t device_exclusive_scan(const T* in, T* out, size_t n, hipStream_t st) {
+  size_t tmp_bytes = 0;
+  hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (T)0, n, rocprim::plus<T>(), st);
+  if (e != hipSuccess) return e;
+  void* tmp = nullptr;
+  e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e != hipSuccess) return e;
+  e = rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (T)0, n, rocprim::plus<T>(), st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  return e != hipSuccess ? e : e2;
+}
+
 }  // namespace miba

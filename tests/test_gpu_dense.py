@@ -75,12 +75,13 @@ def dense_path():
         os.environ["MIBA_EXACT"] = old
 
 
-@pytest.fixture(params=["planned", "atomics"])
+@pytest.fixture(params=["planned", "planned_host", "atomics"])
 def assembly(request):
-    """Both assembly kernels: the host-planned, atomic-free k_dense_blocks (default) and k_dense_pairs /
-    k_dense_pairs_giant (global atomics, used when the pair plan would be too large)."""
+    """Both assembly kernels: the planned, atomic-free k_dense_blocks (default; instance list sorted on the device, or by the
+    host threads: MIBA_DENSE_PLAN=host) and k_dense_pairs / k_dense_pairs_giant (global atomics, used when the pair plan
+    would be too large)."""
     old = os.environ.get("MIBA_DENSE_PLAN")
-    os.environ["MIBA_DENSE_PLAN"] = "0" if request.param == "atomics" else "1"
+    os.environ["MIBA_DENSE_PLAN"] = {"atomics": "0", "planned_host": "host", "planned": "1"}[request.param]
     yield request.param
     if old is None:
         os.environ.pop("MIBA_DENSE_PLAN", None)
@@ -104,7 +105,7 @@ def test_reduced_system_matches_implicit_operator(medium, assembly):
         out = s.linear_step(1e4, opt, probe=probe)
         S = s.reduced_system()
         assert np.array_equal(S, S.T)
-        if assembly == "planned":   # no atomics: the same bits every time
+        if assembly != "atomics":   # no atomics: the same bits every time
             assert S_first is None or np.array_equal(S, S_first)
             S_first = S
         worst = max(worst, rel(S @ probe.ravel(), out["Sv"].ravel()))
@@ -121,6 +122,42 @@ def test_reduced_system_matches_implicit_operator(medium, assembly):
     s.close()
     assert rel(it["y_cam"], out["y_cam"]) <= 1e-5
     assert abs(it["model_cost_change"] - out["model_cost_change"]) <= 1e-8 * abs(out["model_cost_change"])
+
+
+def test_device_plan_is_the_host_plan(medium):
+    """The instance list sorted on the device and the one counting-sorted by the host threads are the same list: S comes
+    out bit for bit the same, on a problem with a long track too (the workgroup-per-point fill)."""
+    rng = np.random.default_rng(3)
+    pr = synth.make_problem(150, 400, 2500, seed=31)
+    pts = np.concatenate([pr["pts"], np.array([[0.2, -0.1, 0.3]])])
+    cs = rng.choice(150, size=140, replace=False).astype(np.int32)
+    ps = np.full(140, 400, dtype=np.int32)
+    xy, z = synth.project(pr["cams"], pts, cs, ps)
+    ok = z < 0
+    assert ok.sum() > 64
+    q = dict(pr)
+    q["n_pt"] = 401
+    q["obs_cam"] = np.concatenate([pr["obs_cam"], cs[ok]]); q["obs_pt"] = np.concatenate([pr["obs_pt"], ps[ok]])
+    q["obs_xy"] = np.concatenate([pr["obs_xy"], xy[ok] + rng.normal(0, 0.5, xy[ok].shape)])
+    cams_l = pr["cams"].copy(); cams_l[:, 0:6] += rng.normal(0, 0.003, (150, 6))
+    pts_l = pts + rng.normal(0, 0.05, pts.shape)
+    for prob in (medium, (q, cams_l, pts_l)):
+        pr_, cams0, pts0 = prob
+        mats = []
+        for plan in ("1", "host"):
+            old = os.environ.get("MIBA_DENSE_PLAN")
+            os.environ["MIBA_DENSE_PLAN"] = plan
+            try:
+                s = make_solver(pr_, cams0, pts0)
+                s.linear_step(1e4, miba.default_options(linear_solver_type=miba.DENSE_SCHUR))
+                mats.append(s.reduced_system())
+                s.close()
+            finally:
+                if old is None:
+                    os.environ.pop("MIBA_DENSE_PLAN", None)
+                else:
+                    os.environ["MIBA_DENSE_PLAN"] = old
+        assert np.array_equal(mats[0], mats[1])
 
 
 def test_exact_step_matches_oracle_dense_schur(oracle, medium):

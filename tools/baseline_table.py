@@ -23,8 +23,6 @@ for name, n_it, cpu_it in (("ladybug-49", 20, 20), ("trafalgar-257", 20, 20), ("
     t_set = time.time() - t0
     rec = {"n_cam": n_cam, "n_pt": n_pt, "n_obs": n_obs, "set_problem_s": round(t_set, 3)}
     for label, lst in (("iterative", miba.ITERATIVE_SCHUR), ("sparse_schur", miba.SPARSE_SCHUR)):
-        if label == "sparse_schur" and n_cam > 20000:   # (the atomic-free assembly plan stops at 20,000 cameras)
-            continue
         vals = []
         for rep in range(3):
             s.set_state(cams0, pts0)
