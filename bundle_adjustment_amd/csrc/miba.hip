@@ -920,6 +920,8 @@ static int dense_plan_device(miba_handle h, bool* done) {
   h->n_dseg = (int32_t)segs.size();
   h->dense_planned = true;
   *done = true;
+  if (getenv("MIBA_DEBUG_PLAN"))
+    fprintf(stderr, "[miba plan] assembly plan on the device: %lld instances, %zu camera blocks, %zu segments\n", (long long)total, nb, segs.size());
   return MIBA_OK;
 }
 

@@ -10,6 +10,7 @@ fi
 run MIBA_POINT_ORDER=0 || exit 1
 run MIBA_FORCE_RCCL=1 || exit 1
 run MIBA_DENSE_PLAN=0 || exit 1
+run MIBA_DENSE_PLAN=host || exit 1
 run MIBA_DEVICE_PLAN=0 || exit 1
 # the tests of the exact solve and the multi-rank runs that use it are left out when it is switched off
 EXTRA="--deselect tests/test_gpu_dense.py --deselect tests/test_gpu_sparse.py --deselect tests/test_gpu_multirank.py"
