@@ -239,53 +239,58 @@ __global__ __launch_bounds__(256) void k_dense_pairs_giant(const Tile* __restric
 // then a cross-lane reduction through LDS.  No atomics unless a block was cut into several segments
 // (seg.w = 1), so S is reproducible bit for bit for all but the very largest blocks.
 constexpr int kDenseSeg = 2048;
-__global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci, first, count, cj | atomic << 30}*/,
-                                                      const int32_t* __restrict__ pts, const double* __restrict__ ct,
-                                                      const double* __restrict__ cm, const double* __restrict__ sc,
-                                                      const double* __restrict__ ptrec, const SDst D) {
-  __shared__ double s_red[4][64 * 9];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int sg = blockIdx.x * 4 + wv;
-  if (sg >= n_seg) return;
-  const int4 Sg = seg[sg];
-  const int ci = __builtin_amdgcn_readfirstlane(Sg.x);
-  const int first = __builtin_amdgcn_readfirstlane(Sg.y), n = __builtin_amdgcn_readfirstlane(Sg.z);
-  const int w4 = __builtin_amdgcn_readfirstlane(Sg.w);
-  const int use_atomic = w4 >> 30, cj = w4 & 0x3FFFFFFF;
-  const SBlock B = sdst_block(D, ci, cj);   // (wave-uniform, requested here: the lookups are back long before the stores)
+// rows [A0, A1) of the 9 x 9 block of one segment, by one wave.  81 accumulators per lane, and the 81 values they are updated
+// from, leave room for one wave per SIMD only, and a single wave issues an fp64 instruction every 8 cycles; two waves that
+// take half of the block's rows each (45 + 36 accumulators; the geometry and G_j computed by both, 1.3 times the
+// instructions) run at two waves per SIMD, twice the issue rate.
+template <int A0, int A1>
+__device__ __forceinline__ void dense_block_rows(const int lane, double* sr, const int ci, const int cj, const int first, const int n,
+                                                 const int use_atomic, const int32_t* __restrict__ pts, const double* __restrict__ ct,
+                                                 const double* __restrict__ cm, const double* __restrict__ sc,
+                                                 const double* __restrict__ ptrec, const SBlock B) {
+  constexpr int NA = A1 - A0;
   double cdi[kCamLds], cdj[kCamLds], sci[9], scj[9];
   mf_stage_cam_init(cdi, ci, ct, cm);
   mf_stage_cam_init(cdj, cj, ct, cm);
 #pragma unroll
   for (int k = 0; k < 9; ++k) { sci[k] = sc[9 * (size_t)ci + k]; scj[k] = sc[9 * (size_t)cj + k]; }
-  double acc[81];
+  double acc[NA * 9];
 #pragma unroll
-  for (int k = 0; k < 81; ++k) acc[k] = 0.0;
+  for (int k = 0; k < NA * 9; ++k) acc[k] = 0.0;
+  // the point id of the next pass is in flight while a pass computes (its record is not: the registers for it would cost the
+  // second wave per SIMD, which hides that trip better)
   const int32_t* ptp = pts + first;
   int32_t pt_c = ptp[min(lane, n - 1)];
   for (int i = lane; i < n; i += 64) {
     const int32_t pt_n = ptp[min(i + 64, n - 1)];
-    const double* rp = ptrec + (size_t)kPtRec * (size_t)pt_c;
+    double rec_c[9];
+    {
+      const double* rp = ptrec + (size_t)kPtRec * (size_t)pt_c;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rec_c[k] = rp[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rec_c[3 + k] = rp[6 + k];
+    }
     double Gi[27], Gj[27], T[27];
-    dense_obs_G(cdi, sci, rp[0], rp[1], rp[2], Gi);
-    if (ci != cj) dense_obs_G(cdj, scj, rp[0], rp[1], rp[2], Gj);
+    dense_obs_G(cdi, sci, rec_c[0], rec_c[1], rec_c[2], Gi);
+    if (ci != cj) dense_obs_G(cdj, scj, rec_c[0], rec_c[1], rec_c[2], Gj);
     else {
 #pragma unroll
       for (int m = 0; m < 27; ++m) Gj[m] = Gi[m];
     }
-    dense_WG(rp + 6, Gi, T);
+    dense_WG(rec_c + 3, Gi, T);   // (only the columns A0 .. A1 - 1 of T are used below: the others fall away at compile time)
 #pragma unroll
-    for (int a = 0; a < 9; ++a)
+    for (int a = A0; a < A1; ++a)
 #pragma unroll
-      for (int b = 0; b < 9; ++b) acc[9 * a + b] = fma(T[a], Gj[b], fma(T[9 + a], Gj[9 + b], fma(T[18 + a], Gj[18 + b], acc[9 * a + b])));
+      for (int b = 0; b < 9; ++b)
+        acc[9 * (a - A0) + b] = fma(T[a], Gj[b], fma(T[9 + a], Gj[9 + b], fma(T[18 + a], Gj[18 + b], acc[9 * (a - A0) + b])));
     pt_c = pt_n;
   }
-  double* sr = s_red[wv];
   const int sub = lane / 9, k9 = lane % 9;
 #pragma unroll
-  for (int r = 0; r < 9; ++r) {   // block row r
+  for (int r = A0; r < A1; ++r) {   // block row r
 #pragma unroll
-    for (int k = 0; k < 9; ++k) sr[lane * 9 + k] = acc[9 * r + k];
+    for (int k = 0; k < 9; ++k) sr[lane * 9 + k] = acc[9 * (r - A0) + k];
     __builtin_amdgcn_wave_barrier();
     double a = 0.0;
     if (lane < 63)
@@ -302,6 +307,24 @@ __global__ __launch_bounds__(256) void k_dense_blocks(int n_seg, const int4* __r
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci, first, count, cj | atomic << 30}*/,
+                                                      const int32_t* __restrict__ pts, const double* __restrict__ ct,
+                                                      const double* __restrict__ cm, const double* __restrict__ sc,
+                                                      const double* __restrict__ ptrec, const SDst D) {
+  __shared__ double s_red[4][64 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sg = blockIdx.x * 2 + (wv >> 1);   // two waves per segment, half of the block's rows each
+  if (sg >= n_seg) return;
+  const int4 Sg = seg[sg];
+  const int ci = __builtin_amdgcn_readfirstlane(Sg.x);
+  const int first = __builtin_amdgcn_readfirstlane(Sg.y), n = __builtin_amdgcn_readfirstlane(Sg.z);
+  const int w4 = __builtin_amdgcn_readfirstlane(Sg.w);
+  const int use_atomic = w4 >> 30, cj = w4 & 0x3FFFFFFF;
+  const SBlock B = sdst_block(D, ci, cj);   // (wave-uniform, requested here: the lookups are back long before the stores)
+  if ((wv & 1) == 0) dense_block_rows<0, 5>(lane, s_red[wv], ci, cj, first, n, use_atomic, pts, ct, cm, sc, ptrec, B);
+  else dense_block_rows<5, 9>(lane, s_red[wv], ci, cj, first, n, use_atomic, pts, ct, cm, sc, ptrec, B);
 }
 
 // SCHUR_JACOBI preconditioner (ceres::SCHUR_JACOBI): the block diagonal of S itself needs, per camera,
