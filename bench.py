@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--check-every", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-states", action="store_true", help="skip the two extra initial states of SURVEY 8(d)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact_solve block (SPARSE_SCHUR on the same problem)")
     ap.add_argument("--cpu-iters", type=int, default=4, help="LM iterations of the CPU oracle per repetition")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU baseline (median reported)")
     ap.add_argument("--preconditioner", choices=["jacobi", "schur_jacobi"], default="jacobi",
@@ -354,28 +355,29 @@ def main():
                             "cost_first": its3[0]["cost"], "cost_last": summ3["final_cost"]}
         out["other_initial_states"] = other
         solver.set_state(cams0, pts0)
-        if args.gpus == 1:
-            # the solver type the reference app itself asks for (app/main.cpp:19, a factorisation): explicit Schur complement in
-            # 64 x 64 tiles + blocked Cholesky on the device, same problem and start; a first solve takes the symbolic phase
-            o4 = miba.default_options(max_num_iterations=1, linear_solver_type=miba.SPARSE_SCHUR, function_tolerance=0.0,
-                                      gradient_tolerance=0.0, parameter_tolerance=0.0, **loss_kw)
-            sync()
-            t4 = time.perf_counter()
-            solver.solve(o4)
-            sync()
-            first_s = time.perf_counter() - t4
-            solver.set_state(cams0, pts0)
-            o4.max_num_iterations = 4
-            its4, summ4 = solver.solve(o4)
-            n4 = max(1, len(its4) - 1)
-            out["exact_solve"] = {"linear_solver_type": "SPARSE_SCHUR", "exact_linear_solver": summ4.get("exact_linear_solver"),
-                                  "lm_iterations": n4, "ms_per_lm_iteration": 1e3 * summ4["total_time_in_seconds"] / n4,
-                                  "ms_per_linear_solve": 1e3 * summ4["linear_solver_time_in_seconds"] / n4,
-                                  "first_solve_s": first_s,
-                                  "note": "not the headline: the factorisation-based solver types on the same problem (tiles of the "
-                                          "Schur complement, csrc/miba_sparse.hpp); first_solve_s = one LM iteration including the "
-                                          "symbolic phase and the assembly plan"}
-            solver.set_state(cams0, pts0)
+
+    if args.gpus == 1 and not args.no_exact:
+        # the solver type the reference app itself asks for (app/main.cpp:19, a factorisation): explicit Schur complement in
+        # 64 x 64 tiles + blocked Cholesky on the device, same problem and start; a first solve takes the symbolic phase
+        o4 = miba.default_options(max_num_iterations=1, linear_solver_type=miba.SPARSE_SCHUR, function_tolerance=0.0,
+                                  gradient_tolerance=0.0, parameter_tolerance=0.0, **loss_kw)
+        sync()
+        t4 = time.perf_counter()
+        solver.solve(o4)
+        sync()
+        first_s = time.perf_counter() - t4
+        solver.set_state(cams0, pts0)
+        o4.max_num_iterations = 4
+        its4, summ4 = solver.solve(o4)
+        n4 = max(1, len(its4) - 1)
+        out["exact_solve"] = {"linear_solver_type": "SPARSE_SCHUR", "exact_linear_solver": summ4.get("exact_linear_solver"),
+                              "lm_iterations": n4, "ms_per_lm_iteration": 1e3 * summ4["total_time_in_seconds"] / n4,
+                              "ms_per_linear_solve": 1e3 * summ4["linear_solver_time_in_seconds"] / n4,
+                              "first_solve_s": first_s,
+                              "note": "not the headline: the factorisation-based solver types on the same problem (tiles of the "
+                                      "Schur complement, csrc/miba_sparse.hpp); first_solve_s = one LM iteration including the "
+                                      "symbolic phase and the assembly plan"}
+        solver.set_state(cams0, pts0)
 
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:
         # CPU baseline: the oracle (a port, oracle/ba_oracle.c) on the host cores, same problem, initial state and options,

@@ -7,7 +7,7 @@ O=$R/gpurun_out/r2prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 [ -f $O/kernel_stats.csv ] || timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 -u $R/bench.py --steps 5 --warmup 2 --cpu-iters 0 --no-other-states --ttt 0 > $O/bench_steps5.json 2> $O/bench_steps5.err || exit 1
-python3 $R/tools/kernel_stats_csv.py $O/trace/t_results.db $O/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-iters 0 --no-other-states --ttt 0   (round-2 build; exported from the rocpd database by tools/kernel_stats_csv.py: per-kernel totals over the whole process)" || exit 1
+python3 $R/tools/kernel_stats_csv.py $O/trace/t_results.db $O/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-iters 0 --no-other-states --ttt 0   (round-2 build; exported from the rocpd database by tools/kernel_stats_csv.py: per-kernel totals over the whole process, i.e. set-up, 2 + 5 LM iterations with the PCG, and the five tile factorisations of bench.py's exact_solve block: k_tchol_*, k_dense_blocks)" || exit 1
 python3 $R/tools/gap_analysis.py $O/trace/t_results.db > $O/gaps.txt 2>&1
 export PCG_ITS=12
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p1 -o p -- python3 -u $R/tools/time_k3.py final-13682 5 > $O/p1.log 2>&1 || exit 1
