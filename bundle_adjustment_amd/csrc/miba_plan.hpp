@@ -51,6 +51,24 @@ struct default_init_alloc : std::allocator<T> {
 };
 template <typename T> using raw_vector = std::vector<T, default_init_alloc<T>>;
 
+// the same with the worker's index: fn(t, begin, end), t < returned count; range t precedes range t + 1
+inline unsigned plan_threads(int64_t n, int64_t min_parallel = (1 << 16)) {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char* e = getenv("MIBA_PLAN_THREADS")) t = (unsigned)atoi(e);
+  if (t < 1) t = 1;
+  if (t > 16) t = 16;
+  if (n <= min_parallel) t = 1;
+  return t;
+}
+template <typename F>
+inline void plan_parallel_ranges(int64_t n, unsigned t, F fn) {
+  if (t <= 1) { fn(0u, (int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (unsigned k = 1; k < t; ++k) th.emplace_back(fn, k, n * k / t, n * (k + 1) / t);
+  fn(0u, (int64_t)0, n / t);
+  for (auto& x : th) x.join();
+}
+
 // MIBA_DEBUG_PLAN=1: phase times of the host tiler on stderr
 struct PlanLap {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -178,25 +196,53 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   }
   P.n_active_cam = 0;
   for (int c = 0; c < n_cam; ++c) P.n_active_cam += P.cam_active[c];
-  // --- order active points
-  P.pt_orig.reserve(n_pt);
-  for (int32_t p = 0; p < n_pt; ++p) if (cnt[p] > 0) P.pt_orig.push_back(p);
-  if (point_order == 1) {
-    // stable counting sort by smallest camera index
-    std::vector<int64_t> first(n_cam + 1, 0);
-    for (int32_t p : P.pt_orig) first[mincam[p] + 1]++;
-    for (int c = 0; c < n_cam; ++c) first[c + 1] += first[c];
-    std::vector<int32_t> sorted(P.pt_orig.size());
-    for (int32_t p : P.pt_orig) sorted[first[mincam[p]]++] = p;
-    P.pt_orig.swap(sorted);
+  // --- order active points (threaded over point ranges: 20 M points at the largest configuration)
+  unsigned nthr = plan_threads(n_pt);
+  while (nthr > 1 && (size_t)nthr * (size_t)n_cam > ((size_t)1 << 26)) nthr /= 2;   // (the per-worker camera histograms)
+  {
+    // active points in the caller's order, or stably counting-sorted by smallest camera index: every worker counts its range
+    // (per camera for the sort), the ranges' offsets follow from the counts, every worker writes its range
+    const bool by_cam = point_order == 1;
+    const size_t nbin = by_cam ? (size_t)n_cam : 1;
+    std::vector<int64_t> hist((size_t)nthr * nbin, 0);
+    plan_parallel_ranges(n_pt, nthr, [&](unsigned t, int64_t a, int64_t b) {
+      int64_t* h = hist.data() + (size_t)t * nbin;
+      for (int64_t p = a; p < b; ++p)
+        if (cnt[p] > 0) h[by_cam ? mincam[p] : 0]++;
+    });
+    int64_t run = 0;
+    for (size_t c = 0; c < nbin; ++c)
+      for (unsigned t = 0; t < nthr; ++t) { const int64_t v = hist[(size_t)t * nbin + c]; hist[(size_t)t * nbin + c] = run; run += v; }
+    P.pt_orig.resize((size_t)run);
+    plan_parallel_ranges(n_pt, nthr, [&](unsigned t, int64_t a, int64_t b) {
+      int64_t* h = hist.data() + (size_t)t * nbin;
+      for (int64_t p = a; p < b; ++p)
+        if (cnt[p] > 0) P.pt_orig[(size_t)h[by_cam ? mincam[p] : 0]++] = (int32_t)p;
+    });
   }
   lap("order points");
   const int32_t n_act = (int32_t)P.pt_orig.size();
-  std::vector<int32_t> sorted_of(n_pt, -1);
-  for (int32_t s = 0; s < n_act; ++s) sorted_of[P.pt_orig[s]] = s;
+  raw_vector<int32_t> sorted_of((size_t)n_pt);
+  plan_parallel_for(n_pt, [&](int64_t a, int64_t b) { for (int64_t p = a; p < b; ++p) sorted_of[p] = -1; });
+  plan_parallel_for(n_act, [&](int64_t a, int64_t b) { for (int64_t q = a; q < b; ++q) sorted_of[P.pt_orig[q]] = (int32_t)q; });
   // --- bucket observations by sorted point (stable: file order), then sort each by camera
-  std::vector<int64_t> off(n_act + 1, 0);
-  for (int32_t s = 0; s < n_act; ++s) off[s + 1] = off[s] + cnt[P.pt_orig[s]];
+  raw_vector<int64_t> off((size_t)n_act + 1);
+  {
+    // prefix sum of the observation counts in sorted order, in two threaded passes
+    const unsigned nt2 = plan_threads(n_act);
+    std::vector<int64_t> part(nt2 + 1, 0);
+    plan_parallel_ranges(n_act, nt2, [&](unsigned t, int64_t a, int64_t b) {
+      int64_t sum = 0;
+      for (int64_t q = a; q < b; ++q) sum += cnt[P.pt_orig[q]];
+      part[t + 1] = sum;
+    });
+    for (unsigned t = 0; t < nt2; ++t) part[t + 1] += part[t];
+    off[0] = 0;
+    plan_parallel_ranges(n_act, nt2, [&](unsigned t, int64_t a, int64_t b) {
+      int64_t run = part[t];
+      for (int64_t q = a; q < b; ++q) { run += cnt[P.pt_orig[q]]; off[q + 1] = run; }
+    });
+  }
   // observations of every sorted point, ascending camera, file order among equal cameras: a stable sort of the valid
   // observations by (sorted point, camera).  On the GPU when the caller brings a sorter (miba_set_problem: rocPRIM radix
   // sort), else bucket + per-point sort on the host threads; both give the same permutation.
