@@ -778,6 +778,45 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
 // MIBA_EXACT=dense|sparse|pcg overrides the choice by size (tests).
 enum { kExactNone = 0, kExactDense = 1, kExactSparse = 2 };
 int sparse_symbolic(miba_handle h);
+// Device memory -> pageable host memory through two pinned staging buffers: the DMA of chunk i + 1 runs while the worker threads
+// copy chunk i out.  (A plain hipMemcpy into pageable memory runs at about 5 GB/s here, the bus at ten times that; pinning
+// the destination itself costs as much as the slow copy.)  Synchronous: returns when dst holds the data.
+static hipError_t download_staged(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  constexpr size_t kStage = (size_t)16 << 20;
+  if (bytes < 2 * kStage) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  }
+  void* stage[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipError_t e = hipHostMalloc(&stage[0], kStage);
+  if (e == hipSuccess) e = hipHostMalloc(&stage[1], kStage);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+  const size_t n_chunk = (bytes + kStage - 1) / kStage;
+  auto issue = [&](size_t i) {
+    const size_t len = std::min(kStage, bytes - i * kStage);
+    hipError_t r = hipMemcpyAsync(stage[i & 1], (const char*)src + i * kStage, len, hipMemcpyDeviceToHost, st);
+    return r != hipSuccess ? r : hipEventRecord(ev[i & 1], st);
+  };
+  if (e == hipSuccess) e = issue(0);
+  for (size_t i = 0; i < n_chunk && e == hipSuccess; ++i) {
+    if (i + 1 < n_chunk) e = issue(i + 1);   // (its buffer was emptied by the host copy of chunk i - 1)
+    if (e == hipSuccess) e = hipEventSynchronize(ev[i & 1]);
+    if (e != hipSuccess) break;
+    const size_t len = std::min(kStage, bytes - i * kStage);
+    char* d = (char*)dst + i * kStage;
+    const char* sp = (const char*)stage[i & 1];
+    plan_parallel_for((int64_t)len, [&](int64_t a, int64_t b) { memcpy(d + a, sp + a, (size_t)(b - a)); }, (int64_t)1 << 20);
+  }
+  if (e != hipSuccess) (void)hipStreamSynchronize(st);
+  if (ev[0]) (void)hipEventDestroy(ev[0]);
+  if (ev[1]) (void)hipEventDestroy(ev[1]);
+  if (stage[0]) (void)hipHostFree(stage[0]);
+  if (stage[1]) (void)hipHostFree(stage[1]);
+  return e;
+}
+
 int exact_kind(miba_handle h, const miba_options* o, int* kind) {
   *kind = kExactNone;
   if (o->linear_solver_type == MIBA_ITERATIVE_SCHUR) return MIBA_OK;
@@ -1111,7 +1150,7 @@ int sparse_symbolic(miba_handle h) {
   double free_all = (double)free_b;
   {
     std::vector<int32_t> ocam((size_t)(h->n_slots ? h->n_slots : 1));
-    if (h->n_slots) HIPCHK(h, hipMemcpy(ocam.data(), h->d_ocam, (size_t)h->n_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h->n_slots) HIPCHK(h, download_staged(ocam.data(), h->d_ocam, (size_t)h->n_slots * sizeof(int32_t), h->st));
     std::vector<int32_t> g;
     std::vector<uint64_t> mask(nW);
     for (int32_t q = 0; q < h->n_pt; ++q) {
@@ -1742,9 +1781,8 @@ static int device_plan_sort(void* ctx, int64_t n_obs, int32_t n_pt, const int32_
   }
   if (e == hipSuccess) {
     out.resize((size_t)n_valid);
-    e = hipMemcpyAsync(out.data(), v1, (size_t)n_valid * 4, hipMemcpyDeviceToHost, C.st);
-    if (e == hipSuccess) e = hipMemcpyAsync(sorted_cam, d_cam, (size_t)n_valid * 4, hipMemcpyDeviceToHost, C.st);
-    if (e == hipSuccess) e = hipStreamSynchronize(C.st);
+    e = download_staged(out.data(), v1, (size_t)n_valid * 4, C.st);
+    if (e == hipSuccess) e = download_staged(sorted_cam, d_cam, (size_t)n_valid * 4, C.st);
   }
   lap("  device sort (upload, sort, download)");
   cleanup();
