@@ -160,6 +160,35 @@ def test_device_plan_is_the_host_plan(medium):
         assert np.array_equal(mats[0], mats[1])
 
 
+def test_planned_assembly_with_a_duplicated_observation(medium):
+    """A point that sees one camera twice: the device plan steps aside for the host's (which counts such pairs from both
+    sides), and the planned assembly still agrees with the atomics kernel and with the tiles."""
+    pr, cams0, pts0 = medium
+    q = dict(pr)
+    q["obs_cam"] = np.concatenate([pr["obs_cam"], pr["obs_cam"][5:6]])
+    q["obs_pt"] = np.concatenate([pr["obs_pt"], pr["obs_pt"][5:6]])
+    q["obs_xy"] = np.concatenate([pr["obs_xy"], pr["obs_xy"][5:6] + 0.25])
+    outs = {}
+    for label, env_kw in (("planned", {"MIBA_DENSE_PLAN": "1"}), ("atomics", {"MIBA_DENSE_PLAN": "0"}),
+                          ("tiles", {"MIBA_DENSE_PLAN": "1", "MIBA_EXACT": "sparse"})):
+        old = {k: os.environ.get(k) for k in env_kw}
+        os.environ.update(env_kw)
+        try:
+            s = make_solver(q, cams0, pts0)
+            outs[label] = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.DENSE_SCHUR))
+            s.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    for label in ("atomics", "tiles"):
+        assert outs[label]["n_cg"] == 1
+        assert rel(outs[label]["y_cam"], outs["planned"]["y_cam"]) <= 1e-9, label
+        assert rel(outs[label]["y_pt"], outs["planned"]["y_pt"]) <= 1e-9, label
+
+
 def test_exact_step_matches_oracle_dense_schur(oracle, medium):
     pr, cams0, pts0 = medium
     s = make_solver(pr, cams0, pts0)
