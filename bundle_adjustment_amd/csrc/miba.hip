@@ -1832,9 +1832,9 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   h->pcg_nb = std::min(nblk(p->n_cam, kPcgCams), kPcgMaxBlocks);
   h->red_cpb = 4 * nblk(p->n_cam, 4 * kPcgMaxBlocks);
   h->red_nb = nblk(p->n_cam, h->red_cpb);
-  // the tail kernel of a PCG iteration holds grid barriers: its grid must be resident as a whole.  One 1024-thread workgroup per
-  // compute unit at most; ranks of this process that share the device share its compute units.
-  h->tail_nb = std::max(1, std::min(nblk(p->n_cam, kTailWaves), h->n_cu / std::max(1, h->dev_share)));
+  // the tail kernel of a PCG iteration holds grid barriers: its grid must be resident as a whole.  One workgroup (kTailThreads) per
+  // compute unit at most, one per sixteen cameras on a small problem; ranks of this process that share the device share its compute units.
+  h->tail_nb = std::max(1, std::min(nblk(p->n_cam, 16), h->n_cu / std::max(1, h->dev_share)));
   h->t0 = P.shard_tile[h->cfg.rank];
   h->t1 = P.shard_tile[h->cfg.rank + 1];
   h->n_tiles = h->t1 - h->t0;

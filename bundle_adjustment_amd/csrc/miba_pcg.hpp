@@ -8,7 +8,7 @@
 //   B  alpha; x += alpha p; r -= alpha q; partial Q; z = M^-1 r; partial r.z
 //   -- grid barrier --
 //   C  end-of-iteration test (Q tolerance, limits), beta, p = z + beta p, control block of the next iteration
-// on a grid that is resident as a whole (at most one 1024-thread workgroup per CU), with the barrier on one device-scope
+// on a grid that is resident as a whole (at most one workgroup of kTailThreads per CU), with the barrier on one device-scope
 // counter.  Every workgroup derives the scalars from the same partial arrays in the same order, so all take the same branch.
 // The only data that cross workgroups inside the kernel are those partial sums; they are written and read with device-scope
 // atomic stores and loads, so the barrier needs no release / acquire fence: on gfx950 each such fence writes back or invalidates
@@ -23,12 +23,18 @@
 
 namespace miba {
 
-constexpr int kTailThreads = 1024;
+// 512 threads, eight waves: 256 workgroups of them cover Final-13682's 1,955 wave records in one round, and against sixteen
+// waves the launch fills the device sooner and the sums over the workgroup are shorter (30.0 -> 27.3 us at Final-13682, 30.7 ->
+// 26.7 us per PCG iteration at trafalgar-257).  Sixteen waves keep one round up to 28,672 cameras instead of 14,336.
+#ifndef MIBA_TAIL_THREADS
+#define MIBA_TAIL_THREADS 512
+#endif
+constexpr int kTailThreads = MIBA_TAIL_THREADS;
 constexpr int kTailWaves = kTailThreads / 64;
 constexpr int kTailCams = 7 * kTailWaves;   // cameras per workgroup round: 7 per wave, nine lanes each
 constexpr int kTailBatch = 16;              // slab loads in flight per lane (112 rows per wave and batch)
 
-// sum over the 1024-thread workgroup, the same value in every thread; s16: 16 doubles of LDS
+// sum over the workgroup, the same value in every thread; s16: kTailWaves doubles of LDS
 __device__ __forceinline__ double tail_block_sum(double v, double* s16) {
   v = wave_sum(v);
   __syncthreads();
@@ -163,7 +169,7 @@ __device__ __forceinline__ void tail_sum_partials2(const double* pa, int na, con
 // REDUCE: phase A is part of this launch (one rank); otherwise q and the p.q partials are there already.
 //
 // Lane (sub, k) of a wave owns entry k of camera cam0 + sub (cpw cameras per wave, nine lanes each).  When one round covers all
-// cameras (single: up to 7 x 16 x 256 = 28,672 of them) the entries of x, p, r, b and the row of M^-1 are loaded before the first
+// cameras (single: up to 7 x kTailWaves x 256 = 14,336 of them) the entries of x, p, r, b and the row of M^-1 are loaded before the first
 // barrier and stay in registers through all three phases: after a barrier only the partial sums are fetched.
 //
 // Phase A reads the slab rows of the wave's cameras as ONE contiguous range (the rows of consecutive cameras follow each other):
