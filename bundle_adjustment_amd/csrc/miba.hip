@@ -1150,7 +1150,10 @@ int sparse_symbolic(miba_handle h) {
   double free_all = (double)free_b;
   {
     std::vector<int32_t> ocam((size_t)(h->n_slots ? h->n_slots : 1));
-    if (h->n_slots) HIPCHK(h, download_staged(ocam.data(), h->d_ocam, (size_t)h->n_slots * sizeof(int32_t), h->st));
+    // (ranks of one process may share a device in tests: the staged download frees pinned memory, which waits for the whole
+    // device, a faster rank's all-reduce kernel included; the plain copy waits for nothing but itself)
+    if (h->n_slots && h->grp && h->grp->n > 1) HIPCHK(h, hipMemcpy(ocam.data(), h->d_ocam, (size_t)h->n_slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+    else if (h->n_slots) HIPCHK(h, download_staged(ocam.data(), h->d_ocam, (size_t)h->n_slots * sizeof(int32_t), h->st));
     std::vector<int32_t> g;
     std::vector<uint64_t> mask(nW);
     for (int32_t q = 0; q < h->n_pt; ++q) {
