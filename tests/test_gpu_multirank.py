@@ -117,6 +117,26 @@ def test_peer_allreduce_kernel(single, world):
     check(run(world, "medium", {"MIBA_ALLREDUCE": "peer"}), single)
 
 
+def test_many_cameras_on_three_ranks():
+    """6,000 cameras: with three ranks sharing the device's compute units the grid of the PCG tail no longer covers the cameras
+    in one round (85 workgroups x 8 waves x 7 cameras), so its phases loop; phase A is a launch of its own with the all-reduce
+    behind it.  Same costs and PCG iteration counts as the one-rank run, whose tail does cover them in one round."""
+    pr = synth.make_problem(6000, 40000, 200000, seed=600)
+    cams0, pts0 = synth.perturb(pr, 0.002, 0.03, seed=601)
+    opt = miba.default_options(max_num_iterations=4, linear_solver_type=miba.ITERATIVE_SCHUR, function_tolerance=0.0,
+                               gradient_tolerance=0.0, parameter_tolerance=0.0)
+    res = []
+    for devs in (None, [0, 0, 0]):
+        s = miba.Solver(device_id=0) if devs is None else miba.Solver(devices=devs)
+        s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+        its, summ = s.solve(opt)
+        s.close()
+        res.append(([r["cost"] for r in its], [r["linear_solver_iterations"] for r in its]))
+    assert res[0][1] == res[1][1]
+    assert np.abs(np.array(res[0][0]) - np.array(res[1][0])).max() <= 1e-9 * res[0][0][0]
+    assert res[0][0][-1] < res[0][0][0]
+
+
 def test_callback_verdict_reaches_every_rank():
     """SOLVER_TERMINATE_SUCCESSFULLY from the callback (rank 0, calling thread) stops all ranks in the same iteration"""
     cams0, pts0, oc, op, oxy = problem("medium")
