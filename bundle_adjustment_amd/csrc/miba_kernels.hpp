@@ -392,7 +392,7 @@ __global__ void k_pack_scalars(double* __restrict__ acc, double* __restrict__ su
 // ---------------------------------------------------------------------------------------------
 // acc2 (SCHUR_JACOBI, else null): upper triangle of sum G'WG per camera, subtracted from B before the inversion,
 // so that M is the block diagonal of S itself (the LM diagonal is still taken from F'F).
-__global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const double* __restrict__ acc2, const uint8_t* __restrict__ active,
+__global__ __launch_bounds__(64) void k_cam_blocks(int n_cam, const double* __restrict__ acc, const double* __restrict__ acc2, const uint8_t* __restrict__ active,
                              const double* __restrict__ sc, double inv_radius, double dmin, double dmax,
                              double* __restrict__ Minv /*[n][81], column-major blocks*/, double* __restrict__ Dc2 /*[n][9]*/,
                              double* __restrict__ rhs /*[n][9]*/, double* __restrict__ partial /*[nblk][2]*/,
@@ -400,11 +400,19 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const do
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   double gmax = 0.0, g2 = 0.0;
   if (c < n_cam) {
+    // (every loop below has compile-time bounds and is unrolled: L stays in registers.  With the early exit the factorisation
+    // loop used to have, L was indexed dynamically and lived in scratch memory: 1.2 KB per lane, which the runtime backs for
+    // every wave slot of the device, 0.64 GB held for as long as the process lives.)
     const double* a = acc + (size_t)kK2W * c;
     double L[81];
-    int o = 0;
-    for (int i = 0; i < 9; ++i)
-      for (int j = i; j < 9; ++j) { L[j * 9 + i] = a[o]; L[i * 9 + j] = a[o]; ++o; }
+    {
+      int o = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = i; j < 9; ++j) { L[j * 9 + i] = a[o]; L[i * 9 + j] = a[o]; ++o; }
+    }
+#pragma unroll
     for (int i = 0; i < 9; ++i) {
       const double d2 = fmin(fmax(L[i * 9 + i], dmin), dmax) * inv_radius;
       Dc2[9 * (size_t)c + i] = d2;
@@ -418,44 +426,52 @@ __global__ void k_cam_blocks(int n_cam, const double* __restrict__ acc, const do
     }
     if (acc2) {
       const double* a2 = acc2 + (size_t)kK2W * c;
-      o = 0;
+      int o = 0;
+#pragma unroll
       for (int i = 0; i < 9; ++i)
+#pragma unroll
         for (int j = i; j < 9; ++j) { L[j * 9 + i] -= a2[o]; if (j != i) L[i * 9 + j] -= a2[o]; ++o; }
     }
-    // in-place lower Cholesky
+    // in-place lower Cholesky (a non-positive pivot is noted and replaced by 1: the result is discarded then)
     bool ok = true;
-    for (int j = 0; j < 9 && ok; ++j) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
       double d = L[j * 9 + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) d -= L[j * 9 + k] * L[j * 9 + k];
-      if (!(d > 0.0)) { ok = false; break; }
+      if (!(d > 0.0)) { ok = false; d = 1.0; }
       d = sqrt(d);
       L[j * 9 + j] = d;
+#pragma unroll
       for (int i = j + 1; i < 9; ++i) {
         double s = L[i * 9 + j];
+#pragma unroll
         for (int k = 0; k < j; ++k) s -= L[i * 9 + k] * L[j * 9 + k];
         L[i * 9 + j] = s / d;
       }
     }
     double* Mi = Minv + 81 * (size_t)c;
-    if (!ok) {
-      ctl->fail = 1;
-      for (int i = 0; i < 81; ++i) Mi[i] = 0.0;
-    } else {
-      // solve L L' col = e_j for each j
-      for (int j = 0; j < 9; ++j) {
-        double col[9];
-        for (int i = 0; i < 9; ++i) {
-          double s = (i == j) ? 1.0 : 0.0;
-          for (int k = 0; k < i; ++k) s -= L[i * 9 + k] * col[k];
-          col[i] = s / L[i * 9 + i];
-        }
-        for (int i = 8; i >= 0; --i) {
-          double s = col[i];
-          for (int k = i + 1; k < 9; ++k) s -= L[k * 9 + i] * col[k];
-          col[i] = s / L[i * 9 + i];
-        }
-        for (int i = 0; i < 9; ++i) Mi[j * 9 + i] = col[i];   // column-major: entry (i, j) at 9 j + i (the PCG kernels read it lane = row)
+    if (!ok) ctl->fail = 1;
+    // solve L L' col = e_j for each j
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      double col[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i * 9 + k] * col[k];
+        col[i] = s / L[i * 9 + i];
       }
+#pragma unroll
+      for (int i = 8; i >= 0; --i) {
+        double s = col[i];
+#pragma unroll
+        for (int k = i + 1; k < 9; ++k) s -= L[k * 9 + i] * col[k];
+        col[i] = s / L[i * 9 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Mi[j * 9 + i] = ok ? col[i] : 0.0;   // column-major: entry (i, j) at 9 j + i (the PCG kernels read it lane = row)
     }
   }
   // launched with 64-thread blocks (one wavefront): wave reductions, NOT the 256-thread block_sum / block_max
