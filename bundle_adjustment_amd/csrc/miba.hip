@@ -26,6 +26,7 @@
 #include "../../include/miba.h"
 #include "miba_kernels.hpp"
 #include "miba_mf.hpp"
+#include "miba_mf2.hpp"
 #include "miba_pcg.hpp"
 #include "miba_dense.hpp"
 #include "miba_sparse.hpp"
@@ -161,6 +162,9 @@ struct miba_handle_s {
   double *d_oxy = nullptr, *d_cam = nullptr, *d_cam_cand = nullptr, *d_ct = nullptr, *d_sc = nullptr;
   double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
+  // camera-major sub-tile layout of the product (miba_mf2.hpp); k3_cm = 0: the point-major product (MIBA_K3=pm, tests / A-B)
+  CmTile* d_cmt = nullptr; CmSub* d_cms = nullptr; uint2* d_cmi = nullptr; int32_t* d_cmrow = nullptr;
+  int k3_cm = 1;
   // camera-major copy of the local observations (K2-mf camera side): segments of one camera each
   int4* d_seg = nullptr; int32_t* d_cmo_pt = nullptr; double2* d_cmo_xy = nullptr; int32_t* d_cam_seg_off = nullptr;
   double* d_slabB = nullptr;
@@ -602,6 +606,10 @@ void mf_matvec_tiles(miba_handle h, const double* x, Ctl* ctl, int pcg_iter, boo
       h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec,        \
       (const double*)h->d_omega, x, h->d_slab9, ctl
   if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_matvec<true>, MIBA_MATVEC_ARGS);
+  else if (h->k3_cm)
+    hipLaunchKernelGGL(k_mf_matvec_cm, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant,
+                       h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec, x,
+                       h->d_slab9, ctl, CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmrow});
   else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
 #undef MIBA_MATVEC_ARGS
 }
@@ -1723,6 +1731,25 @@ int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid
   return MIBA_OK;
 }
 
+int miba_plan_product_stats(const miba_problem* p, double* out8) {
+  if (!p || !out8) return fail(nullptr, MIBA_ERR_INVALID, "null argument");
+  Plan P;
+  const char* po = getenv("MIBA_POINT_ORDER");
+  int rc = build_plan(P, p->n_cam, p->n_pt, p->n_obs, p->obs_cam, p->obs_pt, p->obs_xy, p->X, 1, po ? atoi(po) : 1);
+  if (rc) return fail(nullptr, rc == -6 ? MIBA_ERR_LIMIT : MIBA_ERR_INVALID, "invalid problem (rc=%d)", rc);
+  CmLayout L;
+  build_cm_layout(L, P.tiles, P.groups, P.idx.data(), P.pt_first.data(), P.pt_count.data());
+  CmStats S;
+  const bool ok = cm_layout_stats(L, P.tiles, P.groups, P.idx.data(), P.pt_first.data(), P.pt_count.data(), S);
+  int64_t n_giant_obs = 0;
+  for (const Tile& T : P.tiles)
+    if (T.giant) n_giant_obs += T.ncs;
+  out8[0] = ok ? 1.0 : 0.0;
+  out8[1] = (double)S.n_obs; out8[2] = (double)S.n_entries; out8[3] = (double)S.n_sub; out8[4] = (double)S.n_seg;
+  out8[5] = S.pt_mult; out8[6] = S.cam_mult; out8[7] = (double)n_giant_obs;
+  return MIBA_OK;
+}
+
 int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* owner) {
   if (!p || !owner) return fail(nullptr, MIBA_ERR_INVALID, "null argument");
   Plan P;
@@ -1921,6 +1948,24 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
     pt_rng[q].y = P.pt_count[h->pt_base + q];
   }
   lap("local arrays (oxy, ranges)");
+  // camera-major sub-tiles of the product kernel (miba_mf2.hpp)
+  CmLayout cml;
+  {
+    const char* e = getenv("MIBA_K3");
+    h->k3_cm = !(e && !strcmp(e, "pm"));
+    if (h->k3_cm) {
+      std::vector<int32_t> pf(h->n_pt ? h->n_pt : 1), pc(h->n_pt ? h->n_pt : 1);
+      for (int32_t q = 0; q < h->n_pt; ++q) { pf[q] = pt_rng[q].x; pc[q] = pt_rng[q].y; }
+      build_cm_layout(cml, tiles, grps, P.idx.data() + h->slot_base, pf.data(), pc.data());
+      // small tiles (small problems: a tile per compute unit matters more there) leave the sub-tiles' lanes mostly empty:
+      // the point-major product is the better kernel then
+      int64_t segs = 0;
+      for (const CmSub& sb : cml.subs) segs += sb.nseg;
+      const char* force = getenv("MIBA_K3");
+      if (!(force && !strcmp(force, "cm")) && segs * 4 < (int64_t)cml.subs.size() * kCmLanes * 3) { h->k3_cm = 0; cml = CmLayout(); }
+    }
+  }
+  lap("camera-major sub-tiles (K3)");
   // camera-major copy of the local observations, cut into segments of at most kSegObs observations of one camera
   std::vector<int4> segv;
   std::vector<int32_t> cmo_pt(dev_repack ? (size_t)1 : (size_t)(h->n_obs_local ? h->n_obs_local : 1)), cam_seg_off((size_t)p->n_cam + 1, 0);
@@ -1991,6 +2036,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   for (size_t i = 0; i < tiles.size(); ++i) if (tiles[i].giant) giant.push_back((int32_t)i);
   h->n_giant = (int32_t)giant.size();
   ALLOC(h->d_giant, giant.size());
+  ALLOC(h->d_cmt, cml.tiles.size()); ALLOC(h->d_cms, cml.subs.size()); ALLOC(h->d_cmi, cml.idx.size()); ALLOC(h->d_cmrow, cml.rowinfo.size());
   ALLOC(h->d_cmo_pt, h->n_obs_local ? h->n_obs_local : 1); ALLOC(h->d_cmo_xy, h->n_obs_local ? h->n_obs_local : 1);
   ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_cfree, 9 * nc);
   if (!dev_repack) { ALLOC(h->d_seg, segv.size()); ALLOC(h->d_slabB, (size_t)kK2W * segv.size()); }
@@ -2026,6 +2072,10 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   UP(h->d_wl, wlv.data(), wlv.size());
   UP(h->d_cam_active, P.cam_active.data(), nc);
   UP(h->d_giant, giant.data(), giant.size());
+  UP(h->d_cmt, cml.tiles.data(), cml.tiles.size());
+  UP(h->d_cms, cml.subs.data(), cml.subs.size());
+  UP(h->d_cmi, reinterpret_cast<const uint2*>(cml.idx.data()), cml.idx.size());
+  UP(h->d_cmrow, cml.rowinfo.data(), cml.rowinfo.size());
   if (!dev_repack) {
     UP(h->d_oxy, oxy.data(), 2 * ns);
     UP(h->d_seg, segv.data(), segv.size());
@@ -2540,6 +2590,19 @@ int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* a
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   *avg_ms = (double)ms / reps;
+#ifdef MIBA_CM_STAMPS
+  {
+    unsigned long long st[16];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_cm_stamps), sizeof(st)) == hipSuccess) {
+      const double nsub = (double)std::max(1ull, st[5]), nw = (double)std::max(1ull, st[9]);
+      fprintf(stderr, "[cm stamps] cycles per wave and sub-tile: phase1 %.0f  wait2 %.0f  phase1.5 %.0f  wait3 %.0f  phase2 %.0f | per wave and tile: "
+              "prologue %.0f  flush %.0f  total %.0f (sub-tile waves %.0f, tile waves %.0f)\n", st[0] / nsub, st[1] / nsub, st[2] / nsub, st[3] / nsub,
+              st[4] / nsub, st[6] / nw, st[7] / nw, st[8] / nw, nsub, nw);
+      memset(st, 0, sizeof(st));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cm_stamps), st, sizeof(st));
+    }
+  }
+#endif
   return MIBA_OK;
 }
 

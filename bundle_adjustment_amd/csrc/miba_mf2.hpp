@@ -1,0 +1,250 @@
+// miba_mf2.hpp — the implicit-Schur product (K3) over camera-major sub-tiles.
+//
+// Same operator and the same per-observation algebra as k_mf_matvec (miba_mf.hpp: ImplicitSchurComplement::RightMultiply,
+// SURVEY App. B.3), different ownership.  The point-major wavelets of miba_mf.hpp make the point side cheap (lane scans) and
+// pay for the camera side through LDS: 13 ds_read_b128 of the camera record and 9 ds_add_f64 per observation, which is what
+// bounds that kernel (LDS array 81 % busy, 272 LDS cycles per 64 observations, about 150 of them the atomic adds).  Here a
+// lane owns a SEGMENT: kCmSeg observations of one camera (layout: build_cm_layout, miba_plan.hpp).  Per sub-tile
+//   1  the lane reads its camera record once (12 ds_read_b128 per kCmSeg observations) and, per observation, the point from
+//      LDS, rebuilds the Jacobian blocks, forms u = F x and adds E'u to its point's three sums in LDS (3 ds_add_f64);
+//      E, u and p stay in registers
+//   -- workgroup barrier --
+//   1.5  one thread per point: y = -W a (W from the point record), in place
+//   -- workgroup barrier --
+//   2  per observation w = u + E y and the nine raw camera sums F'w, accumulated in REGISTERS over the segment; one set of
+//      nine ds_add_f64 per segment adds them to the tile's camera accumulators.
+// LDS instructions per observation: about 4 + 3 + 3 + 9/4 instead of 36, no lane scans, no run broadcast, and the point
+// records are read as whole consecutive points (no 96-byte gathers).  Tiles with a camera in Ceres' small-angle branch, giant
+// points and solves with a robust loss take the point-major code of miba_mf.hpp (same launch, per-tile decision).
+#pragma once
+
+#include "miba_mf.hpp"
+
+namespace miba {
+
+#ifndef MIBA_CM_WAVES
+#define MIBA_CM_WAVES 3   // waves per SIMD the register allocation aims at (168 VGPRs)
+#endif
+constexpr int kCmPtLds = 6;   // doubles per point in LDS: [X0 X1 | X2 a0 | a1 a2] (a: sum of E'u, then y)
+
+struct CmArgs {
+  const CmTile* tiles;
+  const CmSub* subs;
+  const uint2* idx;   // [sub-tile][256] four 16-bit entries
+  const int32_t* rowinfo;   // per (tile, camera slot): first accumulator row | rows << 8
+};
+
+// MIBA_CM_STAMPS (debug builds): cycles per phase, summed over the waves, in a device array that miba_time_matvec prints
+#ifdef MIBA_CM_STAMPS
+__device__ unsigned long long g_cm_stamps[16];
+#define CM_T(var) const long long var = clock64()
+#define CM_ADD(i, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_cm_stamps[i], (unsigned long long)((b) - (a))); } while (0)
+#else
+#define CM_T(var) do {} while (0)
+#define CM_ADD(i, a, b) do {} while (0)
+#endif
+
+// one sub-tile's worth of LDS point slots: 256 x 6 doubles; two of them (double-buffered by sub-tile parity)
+constexpr int kCmPtBuf = kCmMaxPts * kCmPtLds;
+
+__device__ __forceinline__ void mf_matvec_cm_tile(const Tile& t, const CmTile ctile, const CmArgs& A, const double* __restrict__ ptrec,
+                                                  const double* s_cam, double* s_acc, double* s_pt) {
+  const int tid = threadIdx.x;
+  // stage of sub-tile s: the points' X into s_pt[s & 1], their sums cleared
+  auto stage_write = [&](double* buf, const double x0, const double x1, const double x2, const bool on) {
+    if (on) {
+      double2* d = reinterpret_cast<double2*>(buf + kCmPtLds * tid);
+      d[0] = make_double2(x0, x1);
+      d[1] = make_double2(x2, 0.0);
+      d[2] = make_double2(0.0, 0.0);
+    }
+  };
+  const CmSub* subs = A.subs + ctile.sub0;
+  // prologue: points of sub-tile 0 (the caller's barrier after the camera staging publishes them)
+  CmSub sb = subs[0];
+  {
+    const bool on = tid < sb.npt;
+    const double* rp = ptrec + (size_t)kPtRec * (size_t)(sb.pt0 + (on ? tid : 0));
+    stage_write(s_pt, rp[0], rp[1], rp[2], on);
+  }
+  uint2 w = A.idx[(size_t)ctile.sub0 * kCmLanes + tid];
+  __syncthreads();
+  for (int s = 0; s < ctile.nsub; ++s) {
+    double* buf = s_pt + (s & 1) * kCmPtBuf;
+    double* buf_next = s_pt + ((s + 1) & 1) * kCmPtBuf;
+    // requests for the next sub-tile (points, index words) and this sub-tile's W rows: in flight during phase 1
+    CM_T(c0);
+    const bool more = s + 1 < ctile.nsub;
+    // (the next record is only needed at the end of this trip: its point range follows from this one)
+    const CmSub sn_rec = subs[more ? s + 1 : s];
+    const int n_pt0 = sb.pt0 + sb.npt, n_npt = sb.npt_next;
+    const bool on_n = more && tid < n_npt;
+    const double* rn = ptrec + (size_t)kPtRec * (size_t)(on_n ? n_pt0 + tid : sb.pt0);
+    const double nx0 = rn[0], nx1 = rn[1], nx2 = rn[2];
+    const uint2 w_next = A.idx[(size_t)(ctile.sub0 + (more ? s + 1 : s)) * kCmLanes + tid];
+    const bool on_p = tid < sb.npt;
+    const double* rw = ptrec + (size_t)kPtRec * (size_t)(sb.pt0 + (on_p ? tid : 0)) + 6;
+    double W[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) W[k] = rw[k];
+
+    // ---- phase 1 ----
+    const unsigned e[kCmSeg] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+    const bool seg_on = (e[0] & 0x8000u) != 0;
+    const int cs = (e[0] >> 8) & 63;
+    double sE[kCmSeg][6], su0[kCmSeg], su1[kCmSeg], spx[kCmSeg], spy[kCmSeg];
+    double k1 = 0.0, k2 = 0.0;
+    if (seg_on) {
+      double cd[kCamLds];
+      mf_read_cam(cd, s_cam, cs);
+      k1 = cd[13]; k2 = cd[14];
+#pragma unroll
+      for (int j = 0; j < kCmSeg; ++j) {
+        const int pt = e[j] & 0xFF;
+        double* pp = buf + kCmPtLds * pt;
+        const double2 a = reinterpret_cast<const double2*>(pp)[0], b = reinterpret_cast<const double2*>(pp)[1];
+        MfGeo geo;
+        mf_geom<false>(cd, a.x, a.y, b.x, geo);
+        double u0, u1;
+        mf_forward(geo, cd, a.x, a.y, b.x, u0, u1);
+        if (e[j] & 0x8000u) {
+          atomicAdd(pp + 3, geo.E[0] * u0 + geo.E[3] * u1);
+          atomicAdd(pp + 4, geo.E[1] * u0 + geo.E[4] * u1);
+          atomicAdd(pp + 5, geo.E[2] * u0 + geo.E[5] * u1);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sE[j][k] = geo.E[k];
+        su0[j] = u0; su1[j] = u1; spx[j] = geo.px; spy[j] = geo.py;
+      }
+    }
+    CM_T(c1);
+    __syncthreads();
+    CM_T(c2);
+    // ---- phase 1.5: y = -W a per point; the next sub-tile's points go into the other buffer (every thread has left phase 2
+    // of the sub-tile before, which read it) ----
+    if (on_p) {
+      double* pp = buf + kCmPtLds * tid;
+      const double a0 = pp[3], a1 = pp[4], a2 = pp[5];
+      pp[3] = -(W[0] * a0 + W[1] * a1 + W[3] * a2);
+      pp[4] = -(W[1] * a0 + W[2] * a1 + W[4] * a2);
+      pp[5] = -(W[3] * a0 + W[4] * a1 + W[5] * a2);
+    }
+    stage_write(buf_next, nx0, nx1, nx2, on_n);
+    CM_T(c3);
+    __syncthreads();
+    CM_T(c4);
+    // ---- phase 2 ----
+    if (seg_on) {
+      double o[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) o[k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCmSeg; ++j) {
+        const int pt = e[j] & 0xFF;
+        const double2* pp = reinterpret_cast<const double2*>(buf + kCmPtLds * pt);
+        const double2 a = pp[0], b = pp[1], c = pp[2];
+        const double x0 = a.x, x1 = a.y, x2 = b.x, y0 = b.y, y1 = c.x, y2 = c.y;
+        const bool valid = (e[j] & 0x8000u) != 0;
+        double w0 = su0[j] + sE[j][0] * y0 + sE[j][1] * y1 + sE[j][2] * y2;
+        double w1 = su1[j] + sE[j][3] * y0 + sE[j][4] * y1 + sE[j][5] * y2;
+        w0 = valid ? w0 : 0.0;
+        w1 = valid ? w1 : 0.0;
+        const double e0 = sE[j][0] * w0 + sE[j][3] * w1;
+        const double e1 = sE[j][1] * w0 + sE[j][4] * w1;
+        const double e2 = sE[j][2] * w0 + sE[j][5] * w1;
+        o[0] += x1 * e2 - x2 * e1;
+        o[1] += x2 * e0 - x0 * e2;
+        o[2] += x0 * e1 - x1 * e0;
+        o[3] += e0; o[4] += e1; o[5] += e2;
+        const double n = spx[j] * spx[j] + spy[j] * spy[j];
+        const double d = 1.0 + n * (k1 + k2 * n);
+        const double sg = spx[j] * w0 + spy[j] * w1;
+        const double ns = n * sg;
+        o[6] += d * sg;
+        o[7] += ns;
+        o[8] += n * ns;
+      }
+      double* dst = s_acc + 9 * ((e[1] >> 8) & 127);   // the lane's accumulator row (one of its camera's)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) atomicAdd(dst + k, o[k]);
+    }
+    w = w_next;
+    sb = sn_rec;
+    CM_T(c5);
+    CM_ADD(0, c0, c1); CM_ADD(1, c1, c2); CM_ADD(2, c2, c3); CM_ADD(3, c3, c4); CM_ADD(4, c4, c5); CM_ADD(5, 0, 1);
+  }
+}
+
+// K3 launch: blocks [0, n_giant) take the giant tiles of tile_list, block n_giant + i takes tile i (as k_mf_matvec).
+__global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant, const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                         const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
+                                                         const int32_t* __restrict__ tile_cams, const int32_t* __restrict__ slab_row,
+                                                         const double* __restrict__ ct, const double* __restrict__ cm,
+                                                         const double* __restrict__ sc, const double* __restrict__ X,
+                                                         const double* __restrict__ ptrec, const double* __restrict__ x,
+                                                         double* __restrict__ slab, const Ctl* __restrict__ ctl, const CmArgs A) {
+  // [camera records | accumulator copies (4 point-major, 2 camera-major) | rest of the point slots of the camera-major path]
+  constexpr int kAccDoubles = kAccCopies * kMaxCamSlots * 9;
+  constexpr int kCmAcc = kCmMaxRows * 9;
+  constexpr int kExtra = 2 * kCmPtBuf - (kAccDoubles - kCmAcc);
+  static_assert(kExtra > 0, "point slots overlap the unused accumulator copies");
+  __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
+  __shared__ __align__(16) double s_acc[kAccDoubles + kExtra];
+  __shared__ double s4[4];
+  if (ctl->done) return;
+  CM_T(k0);
+  if ((int)blockIdx.x < n_giant) {
+    mf_matvec_block<true, false>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X, ptrec,
+                                 nullptr, x, slab);
+    return;
+  }
+  const Tile t = tiles[blockIdx.x - n_giant];
+  if (t.giant) return;
+  const CmTile ctile = A.tiles[blockIdx.x - n_giant];
+  const int tid = threadIdx.x;
+  bool small = false;
+  if (tid < t.ncs) {
+    mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, x);
+    small = s_cam[kCamLds * tid + 24] != 0.0;
+  }
+  const int any_small = __syncthreads_or(small);
+  const int acc_stride = t.ncs * 9;
+  if (any_small || ctile.nsub == 0) {
+    for (int i = tid; i < kAccCopies * acc_stride; i += kChunk) s_acc[i] = 0.0;
+    __syncthreads();
+    mf_matvec_tile<true, false>(t, idx, wl, ptrec, nullptr, s_cam, s_acc);
+    __syncthreads();  // every wave's LDS atomics have landed
+    for (int i = tid; i < acc_stride; i += kChunk) {
+      double v = s_acc[i];
+#pragma unroll
+      for (int c = 1; c < kAccCopies; ++c) v += s_acc[c * acc_stride + i];
+      slab[9 * (size_t)slab_row[t.cam0 + i / 9] + i % 9] = v;
+    }
+    return;
+  }
+  for (int i = tid; i < ctile.nrows * 9; i += kChunk) s_acc[i] = 0.0;
+  // (row ranges of the cameras, for the flush: requested here, used after the last sub-tile)
+  int ri[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) ri[m] = (tid + m * kChunk < acc_stride) ? A.rowinfo[t.cam0 + (tid + m * kChunk) / 9] : 0;
+  CM_T(k1);
+  CM_ADD(6, k0, k1);
+  mf_matvec_cm_tile(t, ctile, A, ptrec, s_cam, s_acc, s_acc + kCmAcc);
+  CM_T(k2);
+  __syncthreads();  // every wave's LDS atomics have landed
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int i = tid + m * kChunk;
+    if (i < acc_stride) {
+      const int cs = i / 9, k = i - 9 * cs, r0 = ri[m] & 0xFF, nr = ri[m] >> 8;
+      double v = s_acc[9 * r0 + k];
+      for (int c = 1; c < nr; ++c) v += s_acc[9 * (r0 + c) + k];
+      slab[9 * (size_t)slab_row[t.cam0 + cs] + k] = v;
+    }
+  }
+  CM_T(k3);
+  CM_ADD(7, k2, k3); CM_ADD(8, k0, k3); CM_ADD(9, 0, 1);
+}
+
+}  // namespace miba

@@ -11,9 +11,11 @@
 // on a grid that is resident as a whole (at most one workgroup of kTailThreads per CU), with the barrier on one device-scope
 // counter.  Every workgroup derives the scalars from the same partial arrays in the same order, so all take the same branch.
 // The only data that cross workgroups inside the kernel are those partial sums; they are written and read with device-scope
-// atomic stores and loads, so the barrier needs no release / acquire fence: on gfx950 each such fence writes back or invalidates
-// the L2 of the XCD, and the fences of a grid serialise (measured, tools/micro/grid_barrier_bench.hip: 34 us per barrier for 256
-// workgroups with them, 3.6 us without; 2.0 us for 128 workgroups).
+// atomic stores and loads, so the barrier needs no release / acquire CACHE maintenance: on gfx950 each such fence writes back
+// or invalidates the L2 of the XCD, and the fences of a grid serialise (measured, tools/micro/grid_barrier_bench.hip: 34 us
+// per barrier for 256 workgroups with them, 3.6 us without; 2.0 us for 128 workgroups).  What the barrier does need is
+// ORDER: the partial-sum store and the arrival atomic go to different L2 channels and may complete out of order, so the
+// arriving thread waits for its stores to be acknowledged (s_waitcnt vmcnt(0)) before it arrives.
 // A barrier that is not reached within two seconds (the grid was not resident after all) ends the solve with a failure status
 // instead of hanging.  With several ranks the camera-side sum stays a kernel of its own (the all-reduce sits behind it) and
 // the tail starts at B.
@@ -61,14 +63,16 @@ __device__ __forceinline__ double tail_sum_partials(const double* part, int n, d
 // counter to reach the number of groups times the number of barriers so far.  (Arrivals on ONE counter cost 12 ns each, one
 // after the other: 3.6 us for 256 workgroups in the microbenchmark, 4.5-6 us inside this kernel; the group counters sit in
 // different cache lines and take their arrivals side by side.)  Thread 0 is also the thread that has stored the workgroup's
-// partial sums: it waits for those stores to be acknowledged (workgroup-scope release = s_waitcnt, no cache maintenance) before
-// it arrives.  Returns false when the others did not arrive in time.
+// partial sums: it waits for those stores to be acknowledged before it arrives -- an explicit s_waitcnt vmcnt(0): outside
+// tgsplit mode a workgroup-scope release fence compiles to s_waitcnt lgkmcnt(0) only, which does not cover global stores; the
+// fence stays as the compiler barrier.  Returns false when the others did not arrive in time.
 constexpr int kBarGroup = 16;
 constexpr int kBarStride = 32;   // unsigneds between counters (128 bytes)
 __device__ __forceinline__ bool tail_grid_barrier(unsigned* bar, unsigned n_blocks, int* s_ok) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned g = blockIdx.x / kBarGroup, n_groups = (n_blocks + kBarGroup - 1) / kBarGroup;
     const unsigned size_g = min((unsigned)kBarGroup, n_blocks - g * kBarGroup);
     const unsigned old = __hip_atomic_fetch_add(bar + (1 + g) * kBarStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -181,13 +181,13 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     for (int64_t v : n_ok) P.n_valid += v;
   }
   lap("filter");
-  // Tile size: 16 chunks once that still leaves a thousand tiles (fewer tile prologues and less padding: 3.5 % on the
+  // Tile size: 15 chunks (16 until round 3) once that still leaves a thousand tiles (fewer tile prologues and less padding: 3.5 % on the
   // LM iteration at Final-13682 against 8 chunks, measured with tools/ab_tile_chunks.sh).  Below that the largest power of
   // two that leaves about 600 tiles: a small problem is latency-bound, a workgroup walks its chunks one after the other, and
   // 256 compute units want a tile each (trafalgar-257, 226 k observations: 37.8 us per PCG iteration with 8 chunks, 32.5-34 us
   // with 1-4; dubrovnik-356, 1.26 M: 49.6 us with 8, 55.9 with 2).
   if (max_chunks == 0) {
-    if (P.n_valid >= ((int64_t)4 << 20)) max_chunks = 16;
+    if (P.n_valid >= ((int64_t)4 << 20)) max_chunks = 15;   // (15, not 16: four full camera-major sub-tiles of the product kernel, see build_cm_layout)
     else {
       const int64_t want = P.n_valid / (kChunk * 600);
       max_chunks = 1;
@@ -342,6 +342,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   auto layout_range = [&](size_t t_begin, size_t t_end, Part& Q) {
     std::vector<int32_t> stamp(n_cam, -1), slot_of(n_cam, 0);
     std::vector<int32_t> order, bin_free;
+    std::vector<size_t> bin_order;
     std::vector<std::vector<int32_t>> bins;
     int64_t& slots = Q.slots;
     if (t_begin < t_end) {
@@ -407,12 +408,19 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
           while (first_open < bins.size() && bin_free[first_open] == 0) ++first_open;
         }
         const int32_t tid = (int32_t)ti;
+        // Wavelets of long points (the first bins) alternate with wavelets of short ones (the last bins): every stretch of the
+        // tile then holds about the same number of points per observation, which is what the camera-major sub-tiles of the
+        // product kernel want (at most kCmMaxPts points each; a stretch of two-observation points alone would hit that limit
+        // at half the lanes).  The kernels that walk wavelets do not care about their order.
+        bin_order.resize(bins.size());
+        for (size_t k = 0, lo = 0, hi = bins.size(); k < bins.size(); ++k) bin_order[k] = (k & 1) ? --hi : lo++;
         for (size_t b0 = 0; b0 < bins.size(); b0 += 4) {
           Group G{};
           G.chunk0 = (int32_t)(slots / kChunk);
           G.nchunk = 1;
           G.pt0 = (int32_t)Q.new_orig.size();
-          for (size_t bi = b0; bi < std::min(b0 + 4, bins.size()); ++bi) {
+          for (size_t bk = b0; bk < std::min(b0 + 4, bins.size()); ++bk) {
+            const size_t bi = bin_order[bk];
             for (int32_t s : bins[bi]) {
               const int64_t a = off[s], b = off[s + 1];
               const int32_t L = (int32_t)(b - a);
@@ -542,6 +550,256 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   }
   lap("wavelets + shards");
   return 0;
+}
+
+
+// ---- camera-major sub-tile layout of the product kernel (K3, miba_mf2.hpp) ------------------------------------------
+// The product's per-observation work wants two things at once: the camera record (24 doubles) and a place to add nine
+// camera-side sums, and the point (3 doubles) and a place to add three point-side sums.  The point-major wavelets of the
+// other kernels pay for the camera side through LDS (13 reads and 9 atomic adds per observation).  Here a tile's points are
+// cut into SUB-TILES of at most kCmLanes segments; a segment is kCmSeg observations of ONE camera, owned by one lane: the lane
+// reads the camera record once per segment and keeps the nine sums in registers; the point side goes through LDS (3 atomic
+// adds per observation), with a workgroup barrier between the two halves of the product.
+//   idx [sub-tile][lane] : four 16-bit entries, step j in bits 16 j .. 16 j + 15: point in sub-tile (bits 0-7) | camera slot
+//                          in tile (8-13) | valid (15).  Padding entries repeat the segment's first (point, camera) pair with
+//                          valid = 0, so that their geometry is that of a real observation; a lane without a segment holds 0.
+//   segment s of a sub-tile (cameras ascending) sits in lane (s & 3) * 64 + (s >> 2): the segments of one camera are spread over
+//   the four waves.  Bits 8-14 of entry 1 hold the lane's camera ACCUMULATOR ROW instead of the camera slot: an atomic add
+//   costs 8 LDS cycles per lane on the same address, so a camera with m segments in one wave of some sub-tile of the tile gets
+//   min(8, m rounded up to a power of two) rows (fewer when the tile's kCmMaxRows rows would not suffice), used in turn by its
+//   lanes; the flush at the end of the tile adds a camera's rows up (rowinfo).
+constexpr int kCmSeg = 4;
+constexpr int kCmLanes = 256;
+constexpr int kCmMaxPts = 256;
+constexpr int kCmMaxRows = 128;   // camera accumulator rows of a tile in LDS (9 doubles each)
+struct CmTile { int32_t sub0, nsub, nrows, pad; };   // per local tile (nsub = 0: giant); nrows: camera accumulator rows in LDS
+struct CmSub { int32_t pt0, npt, nseg, npt_next; };    // local point range, segments in use, points of the tile's next sub-tile (0: last)
+struct CmLayout {
+  std::vector<CmTile> tiles;
+  std::vector<CmSub> subs;
+  raw_vector<uint64_t> idx;                       // [subs.size()][kCmLanes]
+  std::vector<int32_t> rowinfo;                   // per (tile, camera slot), parallel to tile_cams: first accumulator row | rows << 8
+  int64_t n_entries = 0, n_valid = 0;             // lane-steps laid out, and those that hold an observation
+};
+
+// tiles / grps: the shard's (local numbering); idx: the shard's slot words (point-in-chunk | camera slot << 8 | ...);
+// pt_first / pt_count: per local point, first local slot and number of observations
+inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const std::vector<Group>& grps, const int32_t* idx,
+                            const int32_t* pt_first_local, const int32_t* pt_count_local) {
+  L = CmLayout();
+  const size_t nt = tiles.size();
+  L.tiles.assign(nt, CmTile{0, 0, 0, 0});
+  {
+    size_t n_rows = 0;
+    for (const Tile& T : tiles) n_rows = std::max(n_rows, (size_t)T.cam0 + (size_t)T.ncs);
+    L.rowinfo.assign(n_rows ? n_rows : 1, 0);
+  }
+  if (!nt) return;
+  struct Part { std::vector<CmSub> subs; std::vector<uint64_t> idx; std::vector<int32_t> nsub, nrows; int64_t n_valid = 0; };
+  const unsigned nthr = std::max(1u, std::min(plan_threads((int64_t)nt, 64), (unsigned)nt));
+  std::vector<Part> parts(nthr);
+  plan_parallel_ranges((int64_t)nt, nthr, [&](unsigned th, int64_t ta, int64_t tb) {
+    Part& Q = parts[th];
+    Q.nsub.assign((size_t)(tb - ta), 0);
+    Q.nrows.assign((size_t)(tb - ta), 0);
+    int cnt[kMaxCamSlots], seg_off[kMaxCamSlots + 1];
+    int next_t[kMaxCamSlots][16];
+    for (int64_t ti = ta; ti < tb; ++ti) {
+      const Tile& T = tiles[(size_t)ti];
+      if (T.giant || T.ngrp == 0) continue;
+      const int32_t p_begin = grps[(size_t)T.grp0].pt0;
+      const Group& Gl = grps[(size_t)(T.grp0 + T.ngrp - 1)];
+      const int32_t p_end = Gl.pt0 + Gl.npt;
+      int32_t p = p_begin;
+      while (p < p_end) {
+        // greedy cut: whole points while the segments fit the lanes and the points fit their 8-bit ids
+        for (int c = 0; c < kMaxCamSlots; ++c) cnt[c] = 0;
+        int segs = 0;
+        int32_t q = p;
+        for (; q < p_end && q - p < kCmMaxPts; ++q) {
+          const int32_t s0 = pt_first_local[q], n = pt_count_local[q];
+          int add = 0;
+          for (int32_t s = s0; s < s0 + n; ++s) {
+            const int cs = (idx[s] >> 8) & 0xFF;
+            if (cnt[cs] % kCmSeg == 0) ++add;
+            ++cnt[cs];
+          }
+          if (segs + add > kCmLanes) {
+            for (int32_t s = s0; s < s0 + n; ++s) --cnt[(idx[s] >> 8) & 0xFF];
+            break;
+          }
+          segs += add;
+        }
+        // (a point has at most kWave observations here, so q > p)
+        seg_off[0] = 0;
+        for (int c = 0; c < kMaxCamSlots; ++c) seg_off[c + 1] = seg_off[c] + (cnt[c] + kCmSeg - 1) / kCmSeg;
+        const size_t base = Q.idx.size();
+        Q.idx.resize(base + kCmLanes, 0);
+        uint64_t* out = Q.idx.data() + base;
+        auto lane_of = [](int seg) { return (seg & 3) * 64 + (seg >> 2); };
+        // Position of an observation in its camera's row.  The three point-side atomic adds of a wave instruction cost
+        // 8 LDS cycles times the largest number of lanes on ONE address (tools/micro/lds_atomic_bench.hip), so the
+        // observations of a point should sit in different (wave, step) classes: position pos of camera c is executed by
+        // wave (seg_off[c] + pos / 4) & 3 at step pos & 3, class (4 seg_off[c] + pos) & 15.  Every observation takes the next
+        // free position of a class its point has not used yet (the classes of a row are filled evenly, so nothing is padded
+        // beyond the row's last segment); with more than sixteen observations the least used class.
+        for (int c = 0; c < kMaxCamSlots; ++c)
+          for (int k = 0; k < 16; ++k) next_t[c][k] = 0;
+        for (int32_t r = p; r < q; ++r) {
+          const int32_t s0 = pt_first_local[r], n = pt_count_local[r];
+          int used[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int32_t s = s0; s < s0 + n; ++s) {
+            const int cs = (idx[s] >> 8) & 0xFF;
+            const int shift = (4 * seg_off[cs]) & 15;
+            int best = -1, best_used = 1 << 30;
+            for (int kk = 0; kk < 16; ++kk) {
+              const int k = (kk + (int)(r - p) + (int)(s - s0)) & 15;
+              const int pos = ((k - shift) & 15) + 16 * next_t[cs][k];
+              if (pos >= cnt[cs]) continue;
+              if (used[k] < best_used) { best = k; best_used = used[k]; if (!best_used) break; }
+            }
+            const int pos = ((best - shift) & 15) + 16 * next_t[cs][best]++;
+            ++used[best];
+            const int lane = lane_of(seg_off[cs] + pos / kCmSeg), step = pos % kCmSeg;
+            const uint64_t e = (uint64_t)(r - p) | ((uint64_t)cs << 8) | 0x8000u;
+            out[lane] |= e << (16 * step);
+            ++Q.n_valid;
+          }
+        }
+        for (int c = 0; c < kMaxCamSlots; ++c) {
+          const int rem = cnt[c] % kCmSeg;
+          if (!rem) continue;
+          const int lane = lane_of(seg_off[c + 1] - 1);
+          const uint64_t e0 = out[lane] & 0x7FFFu;   // the segment's first pair, not valid
+          for (int step = rem; step < kCmSeg; ++step) out[lane] |= e0 << (16 * step);
+        }
+        Q.subs.push_back(CmSub{p, q - p, seg_off[kMaxCamSlots], 0});
+        ++Q.nsub[(size_t)(ti - ta)];
+        p = q;
+      }
+      // accumulator rows of the tile's cameras: from the largest number of segments a camera has in one wave of one sub-tile
+      const int nsub_t = Q.nsub[(size_t)(ti - ta)];
+      uint64_t* tw = Q.idx.data() + (Q.idx.size() - (size_t)nsub_t * kCmLanes);
+      int need[kMaxCamSlots], rows[kMaxCamSlots], base[kMaxCamSlots], seen[kMaxCamSlots];
+      for (int c = 0; c < kMaxCamSlots; ++c) need[c] = 0;
+      for (int k = 0; k < nsub_t * 4; ++k) {   // (sub-tile, wave)
+        for (int c = 0; c < kMaxCamSlots; ++c) seen[c] = 0;
+        for (int l = 0; l < 64; ++l) {
+          const uint64_t w = tw[(size_t)k * 64 + l];
+          if (w & 0x8000u) { const int cs = (int)((w >> 8) & 63); need[cs] = std::max(need[cs], ++seen[cs]); }
+        }
+      }
+      for (int cap = 8; cap >= 1; cap >>= 1) {
+        int total = 0;
+        for (int c = 0; c < T.ncs; ++c) {
+          int r = 1;
+          while (r < need[c] && r < cap) r <<= 1;
+          rows[c] = r; base[c] = total; total += r;
+        }
+        Q.nrows[(size_t)(ti - ta)] = total;
+        if (total <= kCmMaxRows) break;
+      }
+      for (int c = 0; c < T.ncs; ++c) L.rowinfo[(size_t)T.cam0 + c] = base[c] | (rows[c] << 8);   // (tiles own disjoint ranges)
+      for (int k = 0; k < nsub_t * 4; ++k) {
+        for (int c = 0; c < kMaxCamSlots; ++c) seen[c] = 0;
+        for (int l = 0; l < 64; ++l) {
+          uint64_t& w = tw[(size_t)k * 64 + l];
+          if (!(w & 0x8000u)) continue;
+          const int cs = (int)((w >> 8) & 63);
+          const uint64_t row = (uint64_t)(base[cs] + (seen[cs]++ & (rows[cs] - 1)));
+          w = (w & ~((uint64_t)0x7F00u << 16)) | (row << 24);
+        }
+      }
+    }
+  });
+  size_t total_sub = 0;
+  for (auto& Q : parts) total_sub += Q.subs.size();
+  L.subs.reserve(total_sub);
+  L.idx.resize(total_sub * (size_t)kCmLanes);
+  {
+    size_t ti = 0, so = 0;
+    for (unsigned th = 0; th < nthr; ++th) {
+      Part& Q = parts[th];
+      for (size_t k = 0; k < Q.nsub.size(); ++k, ++ti) {
+        L.tiles[ti].sub0 = (int32_t)so;
+        L.tiles[ti].nsub = Q.nsub[k];
+        L.tiles[ti].nrows = Q.nrows[k];
+        so += (size_t)Q.nsub[k];
+      }
+      std::copy(Q.idx.begin(), Q.idx.end(), L.idx.begin() + (size_t)L.subs.size() * kCmLanes);
+      L.subs.insert(L.subs.end(), Q.subs.begin(), Q.subs.end());
+      L.n_valid += Q.n_valid;
+    }
+    // the sub-tiles of a tile cover consecutive points: with the next one's point count in the record, a workgroup can request
+    // the next sub-tile's points without waiting for its record
+    for (const CmTile& T : L.tiles)
+      for (int32_t k = 0; k + 1 < T.nsub; ++k) L.subs[(size_t)(T.sub0 + k)].npt_next = L.subs[(size_t)(T.sub0 + k + 1)].npt;
+  }
+  L.n_entries = (int64_t)total_sub * kCmLanes * kCmSeg;
+}
+
+
+// Diagnostics of a camera-major layout (CPU; miba_plan_product_stats and the layout test): every observation of the shard
+// appears exactly once (returns false otherwise), padding, and the LDS collision figures that price the kernel's atomic adds.
+struct CmStats {
+  int64_t n_obs = 0, n_entries = 0, n_sub = 0, n_seg = 0;
+  double pt_mult = 0.0;    // mean over (sub-tile, wave, step) of the largest number of lanes on one point
+  double cam_mult = 0.0;   // mean over (sub-tile, wave) of the largest number of lanes on one (camera, accumulator copy)
+};
+inline bool cm_layout_stats(const CmLayout& L, const std::vector<Tile>& tiles, const std::vector<Group>& grps, const int32_t* idx,
+                            const int32_t* pt_first_local, const int32_t* pt_count_local, CmStats& S) {
+  S = CmStats();
+  S.n_sub = (int64_t)L.subs.size();
+  int64_t n_ws = 0, n_w = 0;
+  bool ok = true;
+  std::vector<uint8_t> seen;
+  for (size_t ti = 0; ti < tiles.size(); ++ti) {
+    const Tile& T = tiles[ti];
+    const CmTile& C = L.tiles[ti];
+    if (T.giant) { ok = ok && C.nsub == 0; continue; }
+    for (int32_t k = 0; k < C.nsub; ++k) {
+      const CmSub& sb = L.subs[(size_t)(C.sub0 + k)];
+      const uint64_t* w = L.idx.data() + (size_t)(C.sub0 + k) * kCmLanes;
+      S.n_seg += sb.nseg;
+      // expected multiset of (point, camera slot) pairs of the sub-tile's points
+      std::vector<int32_t> want((size_t)sb.npt * kMaxCamSlots, 0);
+      for (int32_t r = 0; r < sb.npt; ++r)
+        for (int32_t s = pt_first_local[sb.pt0 + r]; s < pt_first_local[sb.pt0 + r] + pt_count_local[sb.pt0 + r]; ++s)
+          want[(size_t)r * kMaxCamSlots + ((idx[s] >> 8) & 0xFF)]++;
+      for (int wv = 0; wv < 4; ++wv) {
+        int cam_cnt[kCmMaxRows] = {0};
+        int cmax = 0;
+        for (int step = 0; step < kCmSeg; ++step) {
+          int pt_cnt[kCmMaxPts] = {0};
+          int pmax = 0;
+          for (int l = 0; l < 64; ++l) {
+            const unsigned e = (unsigned)(w[wv * 64 + l] >> (16 * step)) & 0xFFFFu;
+            const unsigned e0 = (unsigned)w[wv * 64 + l] & 0xFFFFu;
+            if (!(e0 & 0x8000u)) { ok = ok && w[wv * 64 + l] == 0; continue; }
+            const int pt = e & 0xFF, cs = (e0 >> 8) & 63;
+            if (step == 1) {   // bits 8-14: the lane's accumulator row, one of its camera's
+              const int row = (e >> 8) & 127, ri = L.rowinfo[(size_t)T.cam0 + cs];
+              ok = ok && row >= (ri & 0xFF) && row < (ri & 0xFF) + (ri >> 8) && row < C.nrows && C.nrows <= kCmMaxRows;
+              cmax = std::max(cmax, ++cam_cnt[row]);
+            } else ok = ok && cs == (int)((e >> 8) & 63);
+            ok = ok && pt < sb.npt;
+            if (!(e & 0x8000u)) continue;
+            if (pt < sb.npt) { want[(size_t)pt * kMaxCamSlots + cs]--; pmax = std::max(pmax, ++pt_cnt[pt]); }
+            ++S.n_obs;
+          }
+          S.pt_mult += pmax; ++n_ws;
+        }
+        S.cam_mult += cmax; ++n_w;
+      }
+      for (int32_t v : want) ok = ok && v == 0;
+      // the sub-tiles of a tile cover its points in order
+      if (k + 1 < C.nsub) ok = ok && sb.npt_next == L.subs[(size_t)(C.sub0 + k + 1)].npt && L.subs[(size_t)(C.sub0 + k + 1)].pt0 == sb.pt0 + sb.npt;
+    }
+  }
+  S.n_entries = L.n_entries;
+  if (n_ws) S.pt_mult /= (double)n_ws;
+  if (n_w) S.cam_mult /= (double)n_w;
+  return ok;
 }
 
 }  // namespace miba

@@ -27,7 +27,7 @@ EXPORTS = [
     "miba_default_options", "miba_create", "miba_create_multi", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
-    "miba_plan_shards", "miba_plan_point_owner", "miba_time_matvec", "miba_set_constant_blocks",
+    "miba_plan_shards", "miba_plan_point_owner", "miba_plan_product_stats", "miba_time_matvec", "miba_set_constant_blocks",
     "miba_get_reduced_system", "miba_dense_spd_solve", "miba_dense_spd_solve_static",
 ]
 STATIC_SOLVE_MAX_N = 1024   # MIBA_STATIC_SOLVE_MAX_N of include/miba.h
@@ -176,6 +176,20 @@ def plan_point_owner(n_cam, n_pt, obs_cam, obs_pt, obs_xy, world_size):
     if rc != 0:
         raise MibaError("miba_plan_point_owner rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
     return owner
+
+
+def plan_product_stats(n_cam, n_pt, obs_cam, obs_pt, obs_xy):
+    """Host-only: the product kernel's camera-major layout of one shard, checked and priced (miba_plan_product_stats)."""
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
+    obs_xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
+    p = Problem(n_cam, n_pt, obs_cam.size, None, None, None, None, _ip(obs_cam), _ip(obs_pt), _dp(obs_xy))
+    out = np.zeros(8)
+    rc = lib().miba_plan_product_stats(C.byref(p), _dp(out))
+    if rc != 0:
+        raise MibaError("miba_plan_product_stats rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
+    return dict(ok=bool(out[0]), n_obs=int(out[1]), n_entries=int(out[2]), n_sub=int(out[3]), n_seg=int(out[4]),
+                pt_mult=float(out[5]), cam_mult=float(out[6]), n_giant_obs=int(out[7]))
 
 
 class Solver:

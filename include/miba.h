@@ -310,6 +310,13 @@ int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid
  * valid observation and is not part of the problem). owner has n_pt entries. */
 int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* owner);
 
+/* Host-only diagnostic of the product kernel's layout (camera-major sub-tiles, csrc/miba_mf2.hpp) for one shard; no counterpart
+ * in the reference (Ceres keeps its block-sparse Jacobian in one layout). out8 = { layout is a permutation of the non-giant
+ * observations (1/0), observations laid out, lane-steps laid out (observations + padding), sub-tiles, segments,
+ * mean largest number of lanes on one point per wave instruction, mean largest number of lanes on one camera accumulator
+ * per wave, observations of giant points (they stay on the point-major path) }. */
+int miba_plan_product_stats(const miba_problem* p, double* out8);
+
 #ifdef __cplusplus
 }
 #endif
