@@ -163,7 +163,7 @@ struct miba_handle_s {
   double *d_ct_cand = nullptr, *d_cm = nullptr, *d_ptrec = nullptr;   // candidate-state camera table; matrix-free table
   int32_t* d_giant = nullptr;                     // local ids of giant tiles
   // camera-major sub-tile layout of the product (miba_mf2.hpp); k3_cm = 0: the point-major product (MIBA_K3=pm, tests / A-B)
-  CmTile* d_cmt = nullptr; CmSub* d_cms = nullptr; uint2* d_cmi = nullptr; int32_t* d_cmrow = nullptr;
+  CmTile* d_cmt = nullptr; CmSub* d_cms = nullptr; uint2* d_cmi = nullptr; int4* d_cam64 = nullptr; uint8_t* d_cmslot = nullptr;
   int k3_cm = 1;
   // camera-major copy of the local observations (K2-mf camera side): segments of one camera each
   int4* d_seg = nullptr; int32_t* d_cmo_pt = nullptr; double2* d_cmo_xy = nullptr; int32_t* d_cam_seg_off = nullptr;
@@ -609,7 +609,7 @@ void mf_matvec_tiles(miba_handle h, const double* x, Ctl* ctl, int pcg_iter, boo
   else if (h->k3_cm)
     hipLaunchKernelGGL(k_mf_matvec_cm, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant,
                        h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec, x,
-                       h->d_slab9, ctl, CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmrow});
+                       h->d_slab9, ctl, CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64});
   else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
 #undef MIBA_MATVEC_ARGS
 }
@@ -1731,7 +1731,8 @@ int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid
   return MIBA_OK;
 }
 
-int miba_plan_product_stats(const miba_problem* p, double* out8) {
+int miba_plan_product_stats(const miba_problem* p, double* out10) {
+  double* out8 = out10;
   if (!p || !out8) return fail(nullptr, MIBA_ERR_INVALID, "null argument");
   Plan P;
   const char* po = getenv("MIBA_POINT_ORDER");
@@ -1746,7 +1747,7 @@ int miba_plan_product_stats(const miba_problem* p, double* out8) {
     if (T.giant) n_giant_obs += T.ncs;
   out8[0] = ok ? 1.0 : 0.0;
   out8[1] = (double)S.n_obs; out8[2] = (double)S.n_entries; out8[3] = (double)S.n_sub; out8[4] = (double)S.n_seg;
-  out8[5] = S.pt_mult; out8[6] = S.cam_mult; out8[7] = (double)n_giant_obs;
+  out8[5] = S.pt_mult; out8[6] = S.cam_mult; out8[7] = (double)n_giant_obs; out8[8] = S.rd_extra; out8[9] = S.at_extra;
   return MIBA_OK;
 }
 
@@ -1965,6 +1966,16 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
       if (!(force && !strcmp(force, "cm")) && segs * 4 < (int64_t)cml.subs.size() * kCmLanes * 3) { h->k3_cm = 0; cml = CmLayout(); }
     }
   }
+  // per (tile, camera slot) at a fixed stride: camera, slab row, accumulator rows (what the product kernel's first loads fetch)
+  std::vector<int4> cam64(h->k3_cm ? tiles.size() * (size_t)kMaxCamSlots : 1, make_int4(0, 0, 0, 0));
+  if (h->k3_cm)
+    for (size_t ti = 0; ti < tiles.size(); ++ti) {
+      if (tiles[ti].giant) continue;
+      for (int c = 0; c < tiles[ti].ncs; ++c) {
+        const size_t e = (size_t)tiles[ti].cam0 + c;
+        cam64[ti * kMaxCamSlots + c] = make_int4(P.tile_cams[tc0 + e], slab_row[e], cml.rowinfo[e], 0);
+      }
+    }
   lap("camera-major sub-tiles (K3)");
   // camera-major copy of the local observations, cut into segments of at most kSegObs observations of one camera
   std::vector<int4> segv;
@@ -2036,7 +2047,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   for (size_t i = 0; i < tiles.size(); ++i) if (tiles[i].giant) giant.push_back((int32_t)i);
   h->n_giant = (int32_t)giant.size();
   ALLOC(h->d_giant, giant.size());
-  ALLOC(h->d_cmt, cml.tiles.size()); ALLOC(h->d_cms, cml.subs.size()); ALLOC(h->d_cmi, cml.idx.size()); ALLOC(h->d_cmrow, cml.rowinfo.size());
+  ALLOC(h->d_cmt, cml.tiles.size()); ALLOC(h->d_cms, cml.subs.size()); ALLOC(h->d_cmi, cml.idx.size()); ALLOC(h->d_cam64, cam64.size()); ALLOC(h->d_cmslot, cml.slot.size());
   ALLOC(h->d_cmo_pt, h->n_obs_local ? h->n_obs_local : 1); ALLOC(h->d_cmo_xy, h->n_obs_local ? h->n_obs_local : 1);
   ALLOC(h->d_cam_seg_off, nc + 1); ALLOC(h->d_cfree, 9 * nc);
   if (!dev_repack) { ALLOC(h->d_seg, segv.size()); ALLOC(h->d_slabB, (size_t)kK2W * segv.size()); }
@@ -2075,7 +2086,8 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   UP(h->d_cmt, cml.tiles.data(), cml.tiles.size());
   UP(h->d_cms, cml.subs.data(), cml.subs.size());
   UP(h->d_cmi, reinterpret_cast<const uint2*>(cml.idx.data()), cml.idx.size());
-  UP(h->d_cmrow, cml.rowinfo.data(), cml.rowinfo.size());
+  UP(h->d_cam64, cam64.data(), cam64.size());
+  UP(h->d_cmslot, cml.slot.data(), cml.slot.size());
   if (!dev_repack) {
     UP(h->d_oxy, oxy.data(), 2 * ns);
     UP(h->d_seg, segv.data(), segv.size());
@@ -2592,14 +2604,16 @@ int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* a
   *avg_ms = (double)ms / reps;
 #ifdef MIBA_CM_STAMPS
   {
-    unsigned long long st[16];
-    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_cm_stamps), sizeof(st)) == hipSuccess) {
+    std::vector<unsigned long long> all((size_t)kCmStampBlocks * 4 * 16);
+    if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_cm_stamps), all.size() * 8) == hipSuccess) {
+      unsigned long long st[16] = {0};
+      for (size_t i = 0; i < all.size(); ++i) st[i & 15] += all[i];
       const double nsub = (double)std::max(1ull, st[5]), nw = (double)std::max(1ull, st[9]);
       fprintf(stderr, "[cm stamps] cycles per wave and sub-tile: phase1 %.0f  wait2 %.0f  phase1.5 %.0f  wait3 %.0f  phase2 %.0f | per wave and tile: "
               "prologue %.0f  flush %.0f  total %.0f (sub-tile waves %.0f, tile waves %.0f)\n", st[0] / nsub, st[1] / nsub, st[2] / nsub, st[3] / nsub,
               st[4] / nsub, st[6] / nw, st[7] / nw, st[8] / nw, nsub, nw);
-      memset(st, 0, sizeof(st));
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cm_stamps), st, sizeof(st));
+      std::fill(all.begin(), all.end(), 0ull);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cm_stamps), all.data(), all.size() * 8);
     }
   }
 #endif
@@ -2845,6 +2859,7 @@ int miba_get_kernel_times(miba_handle h, miba_kernel_times* out) {
   out->n_pt_local = h->n_pt;
   out->n_tiles = h->n_tiles;
   out->n_cam = h->n_cam;
+  out->product_layout = h->k3_cm;
   return MIBA_OK;
 }
 

@@ -25,24 +25,40 @@ namespace miba {
 #ifndef MIBA_CM_WAVES
 #define MIBA_CM_WAVES 3   // waves per SIMD the register allocation aims at (168 VGPRs)
 #endif
-constexpr int kCmPtLds = 6;   // doubles per point in LDS: [X0 X1 | X2 a0 | a1 a2] (a: sum of E'u, then y)
+constexpr int kCmPtLds = 6;   // arrays of kCmMaxPts doubles per sub-tile in LDS: X0, X1, X2, a0, a1, a2 (a: sum of E'u, then y)
 
 struct CmArgs {
   const CmTile* tiles;
   const CmSub* subs;
   const uint2* idx;   // [sub-tile][256] four 16-bit entries
-  const int32_t* rowinfo;   // per (tile, camera slot): first accumulator row | rows << 8
+  const uint8_t* slot;   // [sub-tile][256] LDS slot of the sub-tile's k-th point
+  const int4* cam64;   // [tile][64] per camera slot: {camera, slab row, first accumulator row | rows << 8, 0}: addressed by the
+                       // block index alone, so that a workgroup's first loads already fetch them
 };
 
 // MIBA_CM_STAMPS (debug builds): cycles per phase, summed over the waves, in a device array that miba_time_matvec prints
 #ifdef MIBA_CM_STAMPS
-__device__ unsigned long long g_cm_stamps[16];
+constexpr int kCmStampBlocks = 16384;
+__device__ unsigned long long g_cm_stamps[kCmStampBlocks * 4 * 16];   // [block][wave][16]: plain stores, summed on the host
 #define CM_T(var) const long long var = clock64()
-#define CM_ADD(i, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_cm_stamps[i], (unsigned long long)((b) - (a))); } while (0)
+#define CM_ACC_DECL long long cm_acc[6] = {0, 0, 0, 0, 0, 0}
+#define CM_ACC(i, a, b) cm_acc[i] += (b) - (a)
+#define CM_ACC_FLUSH do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kCmStampBlocks) { for (int i_ = 0; i_ < 6; ++i_) g_cm_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i_] += (unsigned long long)cm_acc[i_]; } } while (0)
+#define CM_ADD(i, a, b) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < kCmStampBlocks) g_cm_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] += (unsigned long long)((b) - (a)); } while (0)
 #else
 #define CM_T(var) do {} while (0)
+#define CM_ACC_DECL do {} while (0)
+#define CM_ACC(i, a, b) do {} while (0)
+#define CM_ACC_FLUSH do {} while (0)
 #define CM_ADD(i, a, b) do {} while (0)
 #endif
+
+// 8-byte LDS read that stays a ds_read_b64 (256 B/clk): left to itself the compiler pairs the reads of two point arrays into a
+// ds_read2st64_b64, which the LDS serves at half that rate
+__device__ __forceinline__ double lds_read64(const double* p) {
+  typedef const volatile __attribute__((address_space(3))) double lds_cvd;
+  return *(lds_cvd*)p;
+}
 
 // one sub-tile's worth of LDS point slots: 256 x 6 doubles; two of them (double-buffered by sub-tile parity)
 constexpr int kCmPtBuf = kCmMaxPts * kCmPtLds;
@@ -50,24 +66,24 @@ constexpr int kCmPtBuf = kCmMaxPts * kCmPtLds;
 __device__ __forceinline__ void mf_matvec_cm_tile(const Tile& t, const CmTile ctile, const CmArgs& A, const double* __restrict__ ptrec,
                                                   const double* s_cam, double* s_acc, double* s_pt) {
   const int tid = threadIdx.x;
-  // stage of sub-tile s: the points' X into s_pt[s & 1], their sums cleared
-  auto stage_write = [&](double* buf, const double x0, const double x1, const double x2, const bool on) {
+  // stage of a sub-tile: X of its k-th point into slot sl of the three X arrays, the point's sums cleared
+  auto stage_write = [&](double* buf, const int sl, const double x0, const double x1, const double x2, const bool on) {
     if (on) {
-      double2* d = reinterpret_cast<double2*>(buf + kCmPtLds * tid);
-      d[0] = make_double2(x0, x1);
-      d[1] = make_double2(x2, 0.0);
-      d[2] = make_double2(0.0, 0.0);
+      buf[sl] = x0; buf[kCmMaxPts + sl] = x1; buf[2 * kCmMaxPts + sl] = x2;
+      buf[3 * kCmMaxPts + sl] = 0.0; buf[4 * kCmMaxPts + sl] = 0.0; buf[5 * kCmMaxPts + sl] = 0.0;
     }
   };
   const CmSub* subs = A.subs + ctile.sub0;
-  // prologue: points of sub-tile 0 (the caller's barrier after the camera staging publishes them)
-  CmSub sb = subs[0];
+  // prologue: points of sub-tile 0 (their range comes with the tile record: nothing here waits for the sub-tile record)
+  int my_slot = A.slot[(size_t)ctile.sub0 * kCmLanes + tid];
   {
-    const bool on = tid < sb.npt;
-    const double* rp = ptrec + (size_t)kPtRec * (size_t)(sb.pt0 + (on ? tid : 0));
-    stage_write(s_pt, rp[0], rp[1], rp[2], on);
+    const bool on = tid < ctile.npt0;
+    const double* rp = ptrec + (size_t)kPtRec * (size_t)(ctile.pt0 + (on ? tid : 0));
+    stage_write(s_pt, my_slot, rp[0], rp[1], rp[2], on);
   }
   uint2 w = A.idx[(size_t)ctile.sub0 * kCmLanes + tid];
+  CmSub sb = subs[0];
+  CM_ACC_DECL;
   __syncthreads();
   for (int s = 0; s < ctile.nsub; ++s) {
     double* buf = s_pt + (s & 1) * kCmPtBuf;
@@ -81,7 +97,9 @@ __device__ __forceinline__ void mf_matvec_cm_tile(const Tile& t, const CmTile ct
     const bool on_n = more && tid < n_npt;
     const double* rn = ptrec + (size_t)kPtRec * (size_t)(on_n ? n_pt0 + tid : sb.pt0);
     const double nx0 = rn[0], nx1 = rn[1], nx2 = rn[2];
-    const uint2 w_next = A.idx[(size_t)(ctile.sub0 + (more ? s + 1 : s)) * kCmLanes + tid];
+    const size_t nxt = (size_t)(ctile.sub0 + (more ? s + 1 : s)) * kCmLanes + tid;
+    const uint2 w_next = A.idx[nxt];
+    const int slot_next = A.slot[nxt];
     const bool on_p = tid < sb.npt;
     const double* rw = ptrec + (size_t)kPtRec * (size_t)(sb.pt0 + (on_p ? tid : 0)) + 6;
     double W[6];
@@ -100,17 +118,16 @@ __device__ __forceinline__ void mf_matvec_cm_tile(const Tile& t, const CmTile ct
       k1 = cd[13]; k2 = cd[14];
 #pragma unroll
       for (int j = 0; j < kCmSeg; ++j) {
-        const int pt = e[j] & 0xFF;
-        double* pp = buf + kCmPtLds * pt;
-        const double2 a = reinterpret_cast<const double2*>(pp)[0], b = reinterpret_cast<const double2*>(pp)[1];
+        double* pp = buf + (e[j] & 0xFF);
+        const double x0 = lds_read64(pp), x1 = lds_read64(pp + kCmMaxPts), x2 = lds_read64(pp + 2 * kCmMaxPts);
         MfGeo geo;
-        mf_geom<false>(cd, a.x, a.y, b.x, geo);
+        mf_geom<false>(cd, x0, x1, x2, geo);
         double u0, u1;
-        mf_forward(geo, cd, a.x, a.y, b.x, u0, u1);
+        mf_forward(geo, cd, x0, x1, x2, u0, u1);
         if (e[j] & 0x8000u) {
-          atomicAdd(pp + 3, geo.E[0] * u0 + geo.E[3] * u1);
-          atomicAdd(pp + 4, geo.E[1] * u0 + geo.E[4] * u1);
-          atomicAdd(pp + 5, geo.E[2] * u0 + geo.E[5] * u1);
+          atomicAdd(pp + 3 * kCmMaxPts, geo.E[0] * u0 + geo.E[3] * u1);
+          atomicAdd(pp + 4 * kCmMaxPts, geo.E[1] * u0 + geo.E[4] * u1);
+          atomicAdd(pp + 5 * kCmMaxPts, geo.E[2] * u0 + geo.E[5] * u1);
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) sE[j][k] = geo.E[k];
@@ -123,27 +140,35 @@ __device__ __forceinline__ void mf_matvec_cm_tile(const Tile& t, const CmTile ct
     // ---- phase 1.5: y = -W a per point; the next sub-tile's points go into the other buffer (every thread has left phase 2
     // of the sub-tile before, which read it) ----
     if (on_p) {
-      double* pp = buf + kCmPtLds * tid;
-      const double a0 = pp[3], a1 = pp[4], a2 = pp[5];
-      pp[3] = -(W[0] * a0 + W[1] * a1 + W[3] * a2);
-      pp[4] = -(W[1] * a0 + W[2] * a1 + W[4] * a2);
-      pp[5] = -(W[3] * a0 + W[4] * a1 + W[5] * a2);
+      double* pp = buf + my_slot;
+      const double a0 = pp[3 * kCmMaxPts], a1 = pp[4 * kCmMaxPts], a2 = pp[5 * kCmMaxPts];
+      pp[3 * kCmMaxPts] = -(W[0] * a0 + W[1] * a1 + W[3] * a2);
+      pp[4 * kCmMaxPts] = -(W[1] * a0 + W[2] * a1 + W[4] * a2);
+      pp[5 * kCmMaxPts] = -(W[3] * a0 + W[4] * a1 + W[5] * a2);
     }
-    stage_write(buf_next, nx0, nx1, nx2, on_n);
+    stage_write(buf_next, slot_next, nx0, nx1, nx2, on_n);
     CM_T(c3);
     __syncthreads();
     CM_T(c4);
     // ---- phase 2 ----
     if (seg_on) {
       double o[9];
+      // the six reads of step j + 1 are issued before step j is computed
+      double r[2][6];
+      {
+        const double* pp = buf + (e[0] & 0xFF);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) o[k] = 0.0;
+        for (int k = 0; k < 6; ++k) r[0][k] = lds_read64(pp + k * kCmMaxPts);
+      }
 #pragma unroll
       for (int j = 0; j < kCmSeg; ++j) {
-        const int pt = e[j] & 0xFF;
-        const double2* pp = reinterpret_cast<const double2*>(buf + kCmPtLds * pt);
-        const double2 a = pp[0], b = pp[1], c = pp[2];
-        const double x0 = a.x, x1 = a.y, x2 = b.x, y0 = b.y, y1 = c.x, y2 = c.y;
+        if (j + 1 < kCmSeg) {
+          const double* pp = buf + (e[j + 1] & 0xFF);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) r[(j + 1) & 1][k] = lds_read64(pp + k * kCmMaxPts);
+        }
+        const double x0 = r[j & 1][0], x1 = r[j & 1][1], x2 = r[j & 1][2];
+        const double y0 = r[j & 1][3], y1 = r[j & 1][4], y2 = r[j & 1][5];
         const bool valid = (e[j] & 0x8000u) != 0;
         double w0 = su0[j] + sE[j][0] * y0 + sE[j][1] * y1 + sE[j][2] * y2;
         double w1 = su1[j] + sE[j][3] * y0 + sE[j][4] * y1 + sE[j][5] * y2;
@@ -152,27 +177,31 @@ __device__ __forceinline__ void mf_matvec_cm_tile(const Tile& t, const CmTile ct
         const double e0 = sE[j][0] * w0 + sE[j][3] * w1;
         const double e1 = sE[j][1] * w0 + sE[j][4] * w1;
         const double e2 = sE[j][2] * w0 + sE[j][5] * w1;
-        o[0] += x1 * e2 - x2 * e1;
-        o[1] += x2 * e0 - x0 * e2;
-        o[2] += x0 * e1 - x1 * e0;
-        o[3] += e0; o[4] += e1; o[5] += e2;
         const double n = spx[j] * spx[j] + spy[j] * spy[j];
         const double d = 1.0 + n * (k1 + k2 * n);
         const double sg = spx[j] * w0 + spy[j] * w1;
         const double ns = n * sg;
-        o[6] += d * sg;
-        o[7] += ns;
-        o[8] += n * ns;
+        if (j == 0) {
+          o[0] = x1 * e2 - x2 * e1; o[1] = x2 * e0 - x0 * e2; o[2] = x0 * e1 - x1 * e0;
+          o[3] = e0; o[4] = e1; o[5] = e2;
+          o[6] = d * sg; o[7] = ns; o[8] = n * ns;
+        } else {
+          o[0] += x1 * e2 - x2 * e1; o[1] += x2 * e0 - x0 * e2; o[2] += x0 * e1 - x1 * e0;
+          o[3] += e0; o[4] += e1; o[5] += e2;
+          o[6] += d * sg; o[7] += ns; o[8] += n * ns;
+        }
       }
       double* dst = s_acc + 9 * ((e[1] >> 8) & 127);   // the lane's accumulator row (one of its camera's)
 #pragma unroll
       for (int k = 0; k < 9; ++k) atomicAdd(dst + k, o[k]);
     }
     w = w_next;
+    my_slot = slot_next;
     sb = sn_rec;
     CM_T(c5);
-    CM_ADD(0, c0, c1); CM_ADD(1, c1, c2); CM_ADD(2, c2, c3); CM_ADD(3, c3, c4); CM_ADD(4, c4, c5); CM_ADD(5, 0, 1);
+    CM_ACC(0, c0, c1); CM_ACC(1, c1, c2); CM_ACC(2, c2, c3); CM_ACC(3, c3, c4); CM_ACC(4, c4, c5); CM_ACC(5, 0, 1);
   }
+  CM_ACC_FLUSH;
 }
 
 // K3 launch: blocks [0, n_giant) take the giant tiles of tile_list, block n_giant + i takes tile i (as k_mf_matvec).
@@ -192,25 +221,33 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
   __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
   __shared__ __align__(16) double s_acc[kAccDoubles + kExtra];
   __shared__ double s4[4];
-  if (ctl->done) return;
+  // first trip to memory: everything that the block index alone addresses
+  const int ti = max(0, (int)blockIdx.x - n_giant);
+  const int tid = threadIdx.x;
+  const int done = ctl->done;
+  const Tile t = tiles[ti];
+  const CmTile ctile = A.tiles[ti];
+  const int4 c64 = A.cam64[(size_t)ti * kMaxCamSlots + (tid & (kMaxCamSlots - 1))];
+  int4 f64[3];   // the flush's cameras: entry tid + 256 m of the tile's (camera, component) pairs
+#pragma unroll
+  for (int m = 0; m < 3; ++m) f64[m] = A.cam64[(size_t)ti * kMaxCamSlots + min((tid + m * kChunk) / 9, kMaxCamSlots - 1)];
+  if (done) return;
   CM_T(k0);
   if ((int)blockIdx.x < n_giant) {
     mf_matvec_block<true, false>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X, ptrec,
                                  nullptr, x, slab);
     return;
   }
-  const Tile t = tiles[blockIdx.x - n_giant];
   if (t.giant) return;
-  const CmTile ctile = A.tiles[blockIdx.x - n_giant];
-  const int tid = threadIdx.x;
   bool small = false;
   if (tid < t.ncs) {
-    mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, x);
+    mf_stage_cam(s_cam + kCamLds * tid, c64.x, ct, cm, sc, x);
     small = s_cam[kCamLds * tid + 24] != 0.0;
   }
-  const int any_small = __syncthreads_or(small);
   const int acc_stride = t.ncs * 9;
-  if (any_small || ctile.nsub == 0) {
+  // a camera in Ceres' small-angle branch (or no camera-major layout for the tile): the point-major code
+  const int any_small = __syncthreads_or(small || ctile.nsub == 0);
+  if (any_small) {
     for (int i = tid; i < kAccCopies * acc_stride; i += kChunk) s_acc[i] = 0.0;
     __syncthreads();
     mf_matvec_tile<true, false>(t, idx, wl, ptrec, nullptr, s_cam, s_acc);
@@ -224,10 +261,6 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
     return;
   }
   for (int i = tid; i < ctile.nrows * 9; i += kChunk) s_acc[i] = 0.0;
-  // (row ranges of the cameras, for the flush: requested here, used after the last sub-tile)
-  int ri[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) ri[m] = (tid + m * kChunk < acc_stride) ? A.rowinfo[t.cam0 + (tid + m * kChunk) / 9] : 0;
   CM_T(k1);
   CM_ADD(6, k0, k1);
   mf_matvec_cm_tile(t, ctile, A, ptrec, s_cam, s_acc, s_acc + kCmAcc);
@@ -237,10 +270,10 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
   for (int m = 0; m < 3; ++m) {
     const int i = tid + m * kChunk;
     if (i < acc_stride) {
-      const int cs = i / 9, k = i - 9 * cs, r0 = ri[m] & 0xFF, nr = ri[m] >> 8;
+      const int cs = i / 9, k = i - 9 * cs, r0 = f64[m].z & 0xFF, nr = f64[m].z >> 8;
       double v = s_acc[9 * r0 + k];
       for (int c = 1; c < nr; ++c) v += s_acc[9 * (r0 + c) + k];
-      slab[9 * (size_t)slab_row[t.cam0 + cs] + k] = v;
+      slab[9 * (size_t)f64[m].y + k] = v;
     }
   }
   CM_T(k3);

@@ -86,7 +86,7 @@ constexpr int kChunk = 256;        // observation slots per chunk = threads per 
 constexpr int kWave = 64;          // a point never straddles a 64-slot wavelet (one wavefront)
 constexpr int kMaxCamSlots = 64;   // distinct cameras per (non-giant) tile: LDS accumulator rows
 constexpr int kSpanSeg = 1 << 15;     // points per independently tiled segment of the point sequence
-constexpr int kMaxChunksPerTile = 8;   // default below 4 M observations (16 above); MIBA_TILE_CHUNKS overrides (1..16)
+constexpr int kMaxChunksPerTile = 8;   // default below 4 M observations (31 above); MIBA_TILE_CHUNKS overrides (1..64)
 constexpr int kJComp = 26;         // doubles stored per observation: F 18, E 6, r 2
 constexpr int kPtRec = 12;        // per-point record: X 0..2 | z = sp.(C^-1 g) 3..5 | W = diag(sp) C^-1 diag(sp) 6..11
 constexpr int kCamTabStride = 48;  // per-camera table row (R 9, t 3, f k1 k2, pad, dR 27, pad)
@@ -146,7 +146,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
   if (n_cam <= 0 || n_pt <= 0 || n_obs < 0 || world_size < 1) return -1;
   if (n_cam >= (1 << 24)) return -6;
   int max_chunks = 0;   // chosen after the filter, when the number of valid observations is known
-  if (const char* e = getenv("MIBA_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 16) max_chunks = v; }
+  if (const char* e = getenv("MIBA_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 64) max_chunks = v; }
   // --- filter (src/BundleAdjustment.cpp:49-60) and count
   std::vector<int32_t> cnt(n_pt, 0);
   std::vector<int32_t> mincam(n_pt, INT32_MAX);
@@ -181,13 +181,15 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
     for (int64_t v : n_ok) P.n_valid += v;
   }
   lap("filter");
-  // Tile size: 15 chunks (16 until round 3) once that still leaves a thousand tiles (fewer tile prologues and less padding: 3.5 % on the
-  // LM iteration at Final-13682 against 8 chunks, measured with tools/ab_tile_chunks.sh).  Below that the largest power of
+  // Tile size: 31 chunks once that still leaves a few thousand tiles.  (Rounds 1-2: 16 chunks, fewer tile prologues and less
+  // padding than 8: 3.5 % on the LM iteration at Final-13682.  Round 3: the product kernel walks a tile as camera-major sub-tiles of
+  // 256 four-observation segments; 31 chunks are eight of them with 98 % of the lanes in use, 16 chunks are 4.1 of them, i.e.
+  // five with 81 %: 70.1 / 73.7 / 74.4 LM iterations per second with 15 / 23 / 31 chunks, tools/ab_bench_r3.sh.)  Below that the largest power of
   // two that leaves about 600 tiles: a small problem is latency-bound, a workgroup walks its chunks one after the other, and
   // 256 compute units want a tile each (trafalgar-257, 226 k observations: 37.8 us per PCG iteration with 8 chunks, 32.5-34 us
   // with 1-4; dubrovnik-356, 1.26 M: 49.6 us with 8, 55.9 with 2).
   if (max_chunks == 0) {
-    if (P.n_valid >= ((int64_t)4 << 20)) max_chunks = 15;   // (15, not 16: four full camera-major sub-tiles of the product kernel, see build_cm_layout)
+    if (P.n_valid >= ((int64_t)4 << 20)) max_chunks = 31;   // eight full camera-major sub-tiles of the product kernel (build_cm_layout)
     else {
       const int64_t want = P.n_valid / (kChunk * 600);
       max_chunks = 1;
@@ -560,7 +562,8 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
 // cut into SUB-TILES of at most kCmLanes segments; a segment is kCmSeg observations of ONE camera, owned by one lane: the lane
 // reads the camera record once per segment and keeps the nine sums in registers; the point side goes through LDS (3 atomic
 // adds per observation), with a workgroup barrier between the two halves of the product.
-//   idx [sub-tile][lane] : four 16-bit entries, step j in bits 16 j .. 16 j + 15: point in sub-tile (bits 0-7) | camera slot
+//   idx [sub-tile][lane] : four 16-bit entries, step j in bits 16 j .. 16 j + 15: LDS slot of the point (bits 0-7; slot[sub-tile][k]
+//                          is the slot of the sub-tile's k-th point) | camera slot
 //                          in tile (8-13) | valid (15).  Padding entries repeat the segment's first (point, camera) pair with
 //                          valid = 0, so that their geometry is that of a real observation; a lane without a segment holds 0.
 //   segment s of a sub-tile (cameras ascending) sits in lane (s & 3) * 64 + (s >> 2): the segments of one camera are spread over
@@ -572,12 +575,14 @@ constexpr int kCmSeg = 4;
 constexpr int kCmLanes = 256;
 constexpr int kCmMaxPts = 256;
 constexpr int kCmMaxRows = 128;   // camera accumulator rows of a tile in LDS (9 doubles each)
-struct CmTile { int32_t sub0, nsub, nrows, pad; };   // per local tile (nsub = 0: giant); nrows: camera accumulator rows in LDS
+struct CmTile { int32_t sub0, nsub, nrows, pt0, npt0, pad0, pad1, pad2; };   // per local tile (nsub = 0: giant); nrows: camera accumulator
+// rows in LDS; pt0, npt0: the point range of the first sub-tile (the workgroup requests those points with the tile's first loads)
 struct CmSub { int32_t pt0, npt, nseg, npt_next; };    // local point range, segments in use, points of the tile's next sub-tile (0: last)
 struct CmLayout {
   std::vector<CmTile> tiles;
   std::vector<CmSub> subs;
   raw_vector<uint64_t> idx;                       // [subs.size()][kCmLanes]
+  raw_vector<uint8_t> slot;                       // [subs.size()][kCmLanes] LDS slot of the sub-tile's k-th point
   std::vector<int32_t> rowinfo;                   // per (tile, camera slot), parallel to tile_cams: first accumulator row | rows << 8
   int64_t n_entries = 0, n_valid = 0;             // lane-steps laid out, and those that hold an observation
 };
@@ -588,14 +593,14 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
                             const int32_t* pt_first_local, const int32_t* pt_count_local) {
   L = CmLayout();
   const size_t nt = tiles.size();
-  L.tiles.assign(nt, CmTile{0, 0, 0, 0});
+  L.tiles.assign(nt, CmTile{0, 0, 0, 0, 0, 0, 0, 0});
   {
     size_t n_rows = 0;
     for (const Tile& T : tiles) n_rows = std::max(n_rows, (size_t)T.cam0 + (size_t)T.ncs);
     L.rowinfo.assign(n_rows ? n_rows : 1, 0);
   }
   if (!nt) return;
-  struct Part { std::vector<CmSub> subs; std::vector<uint64_t> idx; std::vector<int32_t> nsub, nrows; int64_t n_valid = 0; };
+  struct Part { std::vector<CmSub> subs; std::vector<uint64_t> idx; std::vector<uint8_t> slot; std::vector<int32_t> nsub, nrows; int64_t n_valid = 0; };
   const unsigned nthr = std::max(1u, std::min(plan_threads((int64_t)nt, 64), (unsigned)nt));
   std::vector<Part> parts(nthr);
   plan_parallel_ranges((int64_t)nt, nthr, [&](unsigned th, int64_t ta, int64_t tb) {
@@ -604,6 +609,9 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
     Q.nrows.assign((size_t)(tb - ta), 0);
     int cnt[kMaxCamSlots], seg_off[kMaxCamSlots + 1];
     int next_t[kMaxCamSlots][16];
+    int rd_cnt[32][32], at_cnt[64][16];
+    const bool no_color = getenv("MIBA_CM_COLOR") && getenv("MIBA_CM_COLOR")[0] == '0';   // (diagnostic: slots in point order)
+    std::vector<int32_t> place;
     for (int64_t ti = ta; ti < tb; ++ti) {
       const Tile& T = tiles[(size_t)ti];
       if (T.giant || T.ngrp == 0) continue;
@@ -645,6 +653,8 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
         // beyond the row's last segment); with more than sixteen observations the least used class.
         for (int c = 0; c < kMaxCamSlots; ++c)
           for (int k = 0; k < 16; ++k) next_t[c][k] = 0;
+        // (lane | step << 8) of every observation, points in order
+        place.clear();
         for (int32_t r = p; r < q; ++r) {
           const int32_t s0 = pt_first_local[r], n = pt_count_local[r];
           int used[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -660,10 +670,47 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
             }
             const int pos = ((best - shift) & 15) + 16 * next_t[cs][best]++;
             ++used[best];
-            const int lane = lane_of(seg_off[cs] + pos / kCmSeg), step = pos % kCmSeg;
-            const uint64_t e = (uint64_t)(r - p) | ((uint64_t)cs << 8) | 0x8000u;
-            out[lane] |= e << (16 * step);
+            place.push_back(lane_of(seg_off[cs] + pos / kCmSeg) | ((pos % kCmSeg) << 8) | (cs << 16));
             ++Q.n_valid;
+          }
+        }
+        // LDS slot of every point.  The kernel keeps the sub-tile's points as six arrays of 256 doubles (X, and the three sums):
+        // slot s lies in bank pair s mod 32 of all of them.  A wave's 8-byte reads are served 32 lanes at a time, its atomic
+        // adds 16 lanes at a time, one cycle more for every further slot of a bank pair already in use: every point takes a slot
+        // whose bank pair the points sharing a lane group and step with its observations use least.
+        {
+          static_assert(kCmMaxPts == 256, "slot colouring assumes 256 slots, eight per bank pair");
+          memset(rd_cnt, 0, sizeof(rd_cnt));
+          memset(at_cnt, 0, sizeof(at_cnt));
+          int free_per_color[32];
+          for (int c = 0; c < 32; ++c) free_per_color[c] = 0;
+          const size_t sbase = Q.slot.size();
+          Q.slot.resize(sbase + kCmLanes, 0);
+          size_t o = 0;
+          for (int32_t r = p; r < q; ++r) {
+            const int32_t n = pt_count_local[r];
+            int best = -1, best_cost = 1 << 30;
+            for (int cc = 0; cc < 32; ++cc) {
+              const int c = (cc + (int)(r - p)) & 31;
+              if (free_per_color[c] >= 8) continue;
+              int cost = 0;
+              for (int32_t i = 0; i < n; ++i) {
+                const int pl = place[o + i], lane = pl & 0xFF, step = (pl >> 8) & 3;
+                cost += 9 * rd_cnt[(lane >> 5) * 4 + step][c] + 6 * at_cnt[(lane >> 4) * 4 + step][c & 15];
+              }
+              if (cost < best_cost) { best = c; best_cost = cost; if (!cost) break; }
+            }
+            if (no_color) best = (int)(r - p) & 31;
+            const int slot = best + 32 * free_per_color[best]++;
+            Q.slot[sbase + (size_t)(r - p)] = (uint8_t)slot;
+            for (int32_t i = 0; i < n; ++i) {
+              const int pl = place[o + i], lane = pl & 0xFF, step = (pl >> 8) & 3, cs = pl >> 16;
+              ++rd_cnt[(lane >> 5) * 4 + step][best];
+              ++at_cnt[(lane >> 4) * 4 + step][best & 15];
+              const uint64_t e = (uint64_t)slot | ((uint64_t)cs << 8) | 0x8000u;
+              out[lane] |= e << (16 * step);
+            }
+            o += (size_t)n;
           }
         }
         for (int c = 0; c < kMaxCamSlots; ++c) {
@@ -716,6 +763,7 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
   for (auto& Q : parts) total_sub += Q.subs.size();
   L.subs.reserve(total_sub);
   L.idx.resize(total_sub * (size_t)kCmLanes);
+  L.slot.resize(total_sub * (size_t)kCmLanes);
   {
     size_t ti = 0, so = 0;
     for (unsigned th = 0; th < nthr; ++th) {
@@ -727,13 +775,16 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
         so += (size_t)Q.nsub[k];
       }
       std::copy(Q.idx.begin(), Q.idx.end(), L.idx.begin() + (size_t)L.subs.size() * kCmLanes);
+      std::copy(Q.slot.begin(), Q.slot.end(), L.slot.begin() + (size_t)L.subs.size() * kCmLanes);
       L.subs.insert(L.subs.end(), Q.subs.begin(), Q.subs.end());
       L.n_valid += Q.n_valid;
     }
     // the sub-tiles of a tile cover consecutive points: with the next one's point count in the record, a workgroup can request
     // the next sub-tile's points without waiting for its record
-    for (const CmTile& T : L.tiles)
+    for (CmTile& T : L.tiles) {
       for (int32_t k = 0; k + 1 < T.nsub; ++k) L.subs[(size_t)(T.sub0 + k)].npt_next = L.subs[(size_t)(T.sub0 + k + 1)].npt;
+      if (T.nsub) { T.pt0 = L.subs[(size_t)T.sub0].pt0; T.npt0 = L.subs[(size_t)T.sub0].npt; }
+    }
   }
   L.n_entries = (int64_t)total_sub * kCmLanes * kCmSeg;
 }
@@ -745,6 +796,9 @@ struct CmStats {
   int64_t n_obs = 0, n_entries = 0, n_sub = 0, n_seg = 0;
   double pt_mult = 0.0;    // mean over (sub-tile, wave, step) of the largest number of lanes on one point
   double cam_mult = 0.0;   // mean over (sub-tile, wave) of the largest number of lanes on one (camera, accumulator copy)
+  double rd_extra = 0.0;   // mean over (sub-tile, wave, step): extra LDS cycles of an 8-byte read of a point array (bank pairs hit
+                           // by more than one slot, 32 lanes at a time)
+  double at_extra = 0.0;   // the same for an atomic add (16 lanes at a time), slots on different addresses only
 };
 inline bool cm_layout_stats(const CmLayout& L, const std::vector<Tile>& tiles, const std::vector<Group>& grps, const int32_t* idx,
                             const int32_t* pt_first_local, const int32_t* pt_count_local, CmStats& S) {
@@ -766,27 +820,39 @@ inline bool cm_layout_stats(const CmLayout& L, const std::vector<Tile>& tiles, c
       for (int32_t r = 0; r < sb.npt; ++r)
         for (int32_t s = pt_first_local[sb.pt0 + r]; s < pt_first_local[sb.pt0 + r] + pt_count_local[sb.pt0 + r]; ++s)
           want[(size_t)r * kMaxCamSlots + ((idx[s] >> 8) & 0xFF)]++;
+      // slot -> point of the sub-tile (a bijection onto the slots in use)
+      int inv[kCmMaxPts];
+      for (int k2 = 0; k2 < kCmMaxPts; ++k2) inv[k2] = -1;
+      const uint8_t* slot = L.slot.data() + (size_t)(C.sub0 + k) * kCmLanes;
+      for (int32_t r = 0; r < sb.npt; ++r) { ok = ok && inv[slot[r]] < 0; inv[slot[r]] = r; }
       for (int wv = 0; wv < 4; ++wv) {
         int cam_cnt[kCmMaxRows] = {0};
         int cmax = 0;
         for (int step = 0; step < kCmSeg; ++step) {
           int pt_cnt[kCmMaxPts] = {0};
           int pmax = 0;
+          int rd_load[2][32] = {{0}}, at_load[4][16] = {{0}};
           for (int l = 0; l < 64; ++l) {
             const unsigned e = (unsigned)(w[wv * 64 + l] >> (16 * step)) & 0xFFFFu;
             const unsigned e0 = (unsigned)w[wv * 64 + l] & 0xFFFFu;
             if (!(e0 & 0x8000u)) { ok = ok && w[wv * 64 + l] == 0; continue; }
-            const int pt = e & 0xFF, cs = (e0 >> 8) & 63;
+            const int sl = e & 0xFF, cs = (e0 >> 8) & 63, pt = inv[sl];
             if (step == 1) {   // bits 8-14: the lane's accumulator row, one of its camera's
               const int row = (e >> 8) & 127, ri = L.rowinfo[(size_t)T.cam0 + cs];
               ok = ok && row >= (ri & 0xFF) && row < (ri & 0xFF) + (ri >> 8) && row < C.nrows && C.nrows <= kCmMaxRows;
               cmax = std::max(cmax, ++cam_cnt[row]);
             } else ok = ok && cs == (int)((e >> 8) & 63);
-            ok = ok && pt < sb.npt;
+            ok = ok && pt >= 0;
+            if (pt < 0) continue;
+            if (pt_cnt[pt] == 0) { ++rd_load[l >> 5][sl & 31]; }   // (pads read too; the same slot again is a broadcast)
             if (!(e & 0x8000u)) continue;
-            if (pt < sb.npt) { want[(size_t)pt * kMaxCamSlots + cs]--; pmax = std::max(pmax, ++pt_cnt[pt]); }
+            if (pt_cnt[pt] == 0) ++at_load[l >> 4][sl & 15];
+            want[(size_t)pt * kMaxCamSlots + cs]--;
+            pmax = std::max(pmax, ++pt_cnt[pt]);
             ++S.n_obs;
           }
+          for (int g = 0; g < 2; ++g) { int m = 1; for (int c = 0; c < 32; ++c) m = std::max(m, rd_load[g][c]); S.rd_extra += m - 1; }
+          for (int g = 0; g < 4; ++g) { int m = 1; for (int c = 0; c < 16; ++c) m = std::max(m, at_load[g][c]); S.at_extra += m - 1; }
           S.pt_mult += pmax; ++n_ws;
         }
         S.cam_mult += cmax; ++n_w;
@@ -797,7 +863,7 @@ inline bool cm_layout_stats(const CmLayout& L, const std::vector<Tile>& tiles, c
     }
   }
   S.n_entries = L.n_entries;
-  if (n_ws) S.pt_mult /= (double)n_ws;
+  if (n_ws) { S.pt_mult /= (double)n_ws; S.rd_extra /= (double)n_ws; S.at_extra /= (double)n_ws; }
   if (n_w) S.cam_mult /= (double)n_w;
   return ok;
 }

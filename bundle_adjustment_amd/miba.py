@@ -91,7 +91,7 @@ class Summary(C.Structure):
 class KernelTimes(C.Structure):
     _fields_ = [("launches", C.c_int64 * K_COUNT), ("total_ms", C.c_double * K_COUNT),
                 ("n_slots", C.c_int64), ("n_obs_local", C.c_int64), ("n_pt_local", C.c_int64),
-                ("n_tiles", C.c_int64), ("n_cam", C.c_int32), ("reserved", C.c_int32)]
+                ("n_tiles", C.c_int64), ("n_cam", C.c_int32), ("product_layout", C.c_int32)]
 
 
 CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(Iteration), C.c_void_p)
@@ -184,12 +184,13 @@ def plan_product_stats(n_cam, n_pt, obs_cam, obs_pt, obs_xy):
     obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
     obs_xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
     p = Problem(n_cam, n_pt, obs_cam.size, None, None, None, None, _ip(obs_cam), _ip(obs_pt), _dp(obs_xy))
-    out = np.zeros(8)
+    out = np.zeros(10)
     rc = lib().miba_plan_product_stats(C.byref(p), _dp(out))
     if rc != 0:
         raise MibaError("miba_plan_product_stats rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
     return dict(ok=bool(out[0]), n_obs=int(out[1]), n_entries=int(out[2]), n_sub=int(out[3]), n_seg=int(out[4]),
-                pt_mult=float(out[5]), cam_mult=float(out[6]), n_giant_obs=int(out[7]))
+                pt_mult=float(out[5]), cam_mult=float(out[6]), n_giant_obs=int(out[7]),
+                rd_extra=float(out[8]), at_extra=float(out[9]))
 
 
 class Solver:
@@ -341,7 +342,8 @@ class Solver:
         kt = KernelTimes()
         self._chk(lib().miba_get_kernel_times(self._h, C.byref(kt)), "miba_get_kernel_times")
         return dict(launches=list(kt.launches), total_ms=list(kt.total_ms), n_slots=kt.n_slots,
-                    n_obs_local=kt.n_obs_local, n_pt_local=kt.n_pt_local, n_tiles=kt.n_tiles, n_cam=kt.n_cam)
+                    n_obs_local=kt.n_obs_local, n_pt_local=kt.n_pt_local, n_tiles=kt.n_tiles, n_cam=kt.n_cam,
+                    product_layout=kt.product_layout)
 
     def reset_kernel_times(self):
         self._chk(lib().miba_reset_kernel_times(self._h), "miba_reset_kernel_times")

@@ -212,7 +212,7 @@ typedef struct {
   int64_t n_pt_local;
   int64_t n_tiles;
   int32_t n_cam;
-  int32_t reserved;
+  int32_t product_layout;  /* 1: the implicit-Schur product walks camera-major sub-tiles (csrc/miba_mf2.hpp), 0: point-major wavelets */
 } miba_kernel_times;
 
 void miba_default_options(miba_options* o);
@@ -311,11 +311,12 @@ int miba_plan_shards(const miba_problem* p, int32_t world_size, int64_t* n_valid
 int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* owner);
 
 /* Host-only diagnostic of the product kernel's layout (camera-major sub-tiles, csrc/miba_mf2.hpp) for one shard; no counterpart
- * in the reference (Ceres keeps its block-sparse Jacobian in one layout). out8 = { layout is a permutation of the non-giant
+ * in the reference (Ceres keeps its block-sparse Jacobian in one layout). out10 = { layout is a permutation of the non-giant
  * observations (1/0), observations laid out, lane-steps laid out (observations + padding), sub-tiles, segments,
  * mean largest number of lanes on one point per wave instruction, mean largest number of lanes on one camera accumulator
- * per wave, observations of giant points (they stay on the point-major path) }. */
-int miba_plan_product_stats(const miba_problem* p, double* out8);
+ * per wave, observations of giant points (they stay on the point-major path), mean extra LDS cycles per 8-byte read of a
+ * point array (bank conflicts), the same per atomic add }. */
+int miba_plan_product_stats(const miba_problem* p, double* out10);
 
 #ifdef __cplusplus
 }

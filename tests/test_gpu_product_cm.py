@@ -1,0 +1,178 @@
+"""GPU parity tests of the camera-major product kernel (csrc/miba_mf2.hpp, k_mf_matvec_cm) against the CPU oracle.
+
+The library picks that kernel by itself only where its sub-tiles fill (problems of several million observations: the
+Final-13682 and 150 M-observation cases of test_gpu_configs.py run it); MIBA_K3=cm forces it here on problems the oracle
+finishes in seconds, with tile sizes from one chunk (sub-tiles a quarter full) to sixteen, giant tracks, filtered
+observations, constant blocks, the reference's camera model, a camera in Ceres' small-angle branch (whose tile takes the
+point-major code inside the same launch) and several ranks.  Bars as in test_gpu_parity.py: S*v and the reduced right-hand
+side within 1e-10, PCG iteration counts equal to the oracle's."""
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import miba, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    m = np.abs(b).max()
+    return np.abs(a - b).max() / (m if m > 0 else 1.0)
+
+
+def solver(pr, cams, pts, devices=None, **kw):
+    s = miba.Solver(device_id=0) if devices is None else miba.Solver(devices=devices)
+    s.set_problem(cams, pts, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], **kw)
+    return s
+
+
+def check_step(oracle, pr, cams0, pts0, monkeypatch, chunks, devices=None, want_cm=True):
+    monkeypatch.setenv("MIBA_K3", "cm")
+    monkeypatch.setenv("MIBA_TILE_CHUNKS", str(chunks))
+    probe = np.random.default_rng(5).normal(size=(pr["n_cam"], 9))
+    s = solver(pr, cams0, pts0, devices)
+    assert s.kernel_times()["product_layout"] == (1 if want_cm else 0)
+    out = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, eta=0.1), probe=probe)
+    s.close()
+    sc, sp = oracle.jacobi_scale(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    ref = oracle.linear_step(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], 1e4, sc, sp,
+                             oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, eta=0.1), probe=probe)
+    assert ref["rc"] == 0
+    assert rel(out["rhs"], ref["rhs"]) <= 1e-10
+    assert rel(out["Sv"], ref["Sv"]) <= 1e-10, rel(out["Sv"], ref["Sv"])
+    assert out["n_cg"] == ref["n_cg"], (out["n_cg"], ref["n_cg"])
+    assert rel(out["y_cam"], ref["y_cam"]) <= 1e-7
+    assert rel(out["y_pt"], ref["y_pt"]) <= 1e-7
+    assert abs(out["model_cost_change"] - ref["model_cost_change"]) <= 1e-9 * abs(ref["model_cost_change"])
+
+
+@pytest.fixture(scope="module")
+def medium():
+    pr = synth.make_problem(40, 3000, 14000, seed=11, shuffle_obs=True)
+    cams0, pts0 = synth.perturb(pr, 0.01, 0.1, seed=12)
+    return pr, cams0, pts0
+
+
+@pytest.fixture(scope="module")
+def wide():
+    # more cameras than a tile holds (64): tiles are cut by the camera limit; 120 k observations: up to sixteen chunks per tile
+    pr = synth.make_problem(300, 20000, 120000, seed=21, shuffle_obs=True)
+    cams0, pts0 = synth.perturb(pr, 0.005, 0.05, seed=22)
+    return pr, cams0, pts0
+
+
+@pytest.mark.parametrize("chunks", [1, 4, 16])
+def test_product_matches_oracle(oracle, medium, monkeypatch, chunks):
+    pr, cams0, pts0 = medium
+    check_step(oracle, pr, cams0, pts0, monkeypatch, chunks)
+
+
+@pytest.mark.parametrize("chunks", [3, 8, 31])
+def test_product_matches_oracle_many_cameras(oracle, wide, monkeypatch, chunks):
+    pr, cams0, pts0 = wide
+    check_step(oracle, pr, cams0, pts0, monkeypatch, chunks)
+
+
+def test_giant_tracks_and_filtered_observations(oracle, medium, monkeypatch):
+    """A point seen by every camera several times over (more observations than a wavefront: it keeps the point-major block
+    of the same launch), observations without a point, a NaN measurement."""
+    pr, cams0, pts0 = medium
+    pr = dict(pr)
+    oc, op, xy = pr["obs_cam"].copy(), pr["obs_pt"].copy(), pr["obs_xy"].copy()
+    rng = np.random.default_rng(3)
+    g = rng.choice(oc.size, 150, replace=False)
+    op[g] = 7
+    drop = rng.choice(np.setdiff1d(np.arange(oc.size), g), 40, replace=False)
+    op[drop[:20]] = -1
+    xy[drop[20:], 0] = np.nan
+    keep = (op >= 0) & ~np.isnan(xy[:, 0])
+    monkeypatch.setenv("MIBA_K3", "cm")
+    monkeypatch.setenv("MIBA_TILE_CHUNKS", "4")
+    probe = rng.normal(size=(pr["n_cam"], 9))
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams0, pts0, oc, op, xy)
+    assert s.kernel_times()["product_layout"] == 1
+    out = s.linear_step(1e4, miba.default_options(eta=0.1), probe=probe)
+    s.close()
+    sc, sp = oracle.jacobi_scale(cams0, pts0, oc[keep], op[keep], xy[keep])
+    ref = oracle.linear_step(cams0, pts0, oc[keep], op[keep], xy[keep], 1e4, sc, sp,
+                             oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, eta=0.1), probe=probe)
+    assert rel(out["rhs"], ref["rhs"]) <= 1e-10
+    assert rel(out["Sv"], ref["Sv"]) <= 1e-10
+    assert out["n_cg"] == ref["n_cg"]
+
+
+def test_small_angle_camera_takes_the_point_major_tile(oracle, medium, monkeypatch):
+    """A camera with |w|^2 <= DBL_EPSILON is in Ceres' first-order branch: its tiles run the point-major
+    code inside the camera-major launch; the others do not notice."""
+    pr, cams0, pts0 = medium
+    cams = cams0.copy()
+    cams[3, 0:3] = 0.0
+    cams[17, 0:3] = [1e-9, -2e-9, 5e-10]
+    check_step(oracle, pr, cams, pts0, monkeypatch, 4)
+
+
+def test_constant_blocks(oracle, medium, monkeypatch):
+    """SetParameterBlockConstant as the reference's createProblem uses it (src/BundleAdjustment.cpp:77-79,88-90)."""
+    pr, cams0, pts0 = medium
+    monkeypatch.setenv("MIBA_K3", "cm")
+    monkeypatch.setenv("MIBA_TILE_CHUNKS", "4")
+    cc = np.zeros((pr["n_cam"], 3), dtype=np.uint8)
+    cc[:, 0] = 1
+    cc[:, 2] = 1
+    cc[0, :] = 1
+    probe = np.random.default_rng(9).normal(size=(pr["n_cam"], 9))
+    s = solver(pr, cams0, pts0)
+    s.set_constant_blocks(cc)
+    out = s.linear_step(1e3, miba.default_options(eta=0.1), probe=probe)
+    s.close()
+    sc, sp = oracle.jacobi_scale(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    sc = sc * (1.0 - np.repeat(cc, 3, axis=1))   # a zero scale takes the column out (as bao_solve does)
+    ref = oracle.linear_step(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], 1e3, sc, sp,
+                             oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, eta=0.1), probe=probe)
+    assert rel(out["rhs"], ref["rhs"]) <= 1e-10
+    assert rel(out["Sv"], ref["Sv"]) <= 1e-10
+    assert out["n_cg"] == ref["n_cg"]
+    assert np.all(out["y_cam"][0] == 0.0) and np.all(out["y_cam"][:, 0:3] == 0.0) and np.all(out["y_cam"][:, 6:9] == 0.0)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_several_ranks(oracle, wide, monkeypatch, devices):
+    """Point shards of the camera-major layout: every rank lays out its own tiles; S*v is the all-reduced sum."""
+    pr, cams0, pts0 = wide
+    check_step(oracle, pr, cams0, pts0, monkeypatch, 8, devices=devices)
+
+
+def test_lm_run_equals_point_major_run(medium, monkeypatch):
+    """Whole LM solves with the two product kernels: same accept / reject decisions and PCG counts, costs to 1e-9."""
+    pr, cams0, pts0 = medium
+    opt = miba.default_options(max_num_iterations=12, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    runs = {}
+    for k3 in ("cm", "pm"):
+        monkeypatch.setenv("MIBA_K3", k3)
+        monkeypatch.setenv("MIBA_TILE_CHUNKS", "4")
+        s = solver(pr, cams0, pts0)
+        assert s.kernel_times()["product_layout"] == (1 if k3 == "cm" else 0)
+        runs[k3] = s.solve(opt)
+        s.close()
+    a, b = runs["cm"][0], runs["pm"][0]
+    # (as in test_gpu_configs.py: once an iteration's progress is below 1e-9 of the cost, the decisions sit in rounding noise)
+    n = 0
+    for x, y in zip(a, b):
+        if n > 0 and abs(y["cost_change"]) <= 1e-9 * y["cost"]:
+            break
+        assert x["step_is_successful"] == y["step_is_successful"]
+        assert x["linear_solver_iterations"] == y["linear_solver_iterations"]
+        assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
+        n += 1
+    assert n >= 5
+    assert abs(runs["cm"][1]["final_cost"] - runs["pm"][1]["final_cost"]) <= 1e-9 * runs["pm"][1]["final_cost"]
+
+
+def test_small_tiles_fall_back_by_themselves(medium, monkeypatch):
+    """Without MIBA_K3 the library measures the fill of the sub-tiles: a problem this small keeps the point-major product."""
+    pr, cams0, pts0 = medium
+    monkeypatch.delenv("MIBA_K3", raising=False)
+    monkeypatch.delenv("MIBA_TILE_CHUNKS", raising=False)
+    s = solver(pr, cams0, pts0)
+    assert s.kernel_times()["product_layout"] == 0
+    s.close()

@@ -181,3 +181,30 @@ def test_group_plan_is_the_rank_plan():
         counts = np.bincount(owner[op], minlength=world)
         assert list(counts) == info["obs_per_rank"]
         assert max(info["obs_per_rank"]) <= 1.25 * min(info["obs_per_rank"]) + 4096
+
+
+@pytest.mark.parametrize("chunks", ["2", "8", "31"])
+def test_product_layout_is_a_permutation(chunks, monkeypatch):
+    """The camera-major sub-tile layout of the product kernel (csrc/miba_plan.hpp build_cm_layout, used by csrc/miba_mf2.hpp):
+    every observation of a non-giant point appears exactly once with its own (point, camera) pair, padding entries repeat a
+    real pair, accumulator rows stay inside their camera's range, sub-tiles cover a tile's points in order.  Checked on the
+    CPU by the library's own verifier (miba_plan_product_stats) for three tile sizes and a problem with giant tracks,
+    filtered observations and a point seen twice by one camera."""
+    monkeypatch.setenv("MIBA_TILE_CHUNKS", chunks)
+    pr = synth.make_problem(90, 9000, 60000, seed=5)
+    oc, op, xy = pr["obs_cam"].copy(), pr["obs_pt"].copy(), pr["obs_xy"].copy()
+    # a giant track (more observations than a wavefront), filtered observations, a duplicate (point, camera) pair
+    op[:200] = 17
+    oc[:200] = np.arange(200) % 90
+    op[300:320] = -1
+    xy[330:340, 0] = np.nan
+    oc[401] = oc[400]; op[401] = op[400]
+    st = miba.plan_product_stats(90, 9000, oc, op, xy)
+    assert st["ok"], st
+    valid = (op >= 0) & ~np.isnan(xy[:, 0])
+    counts = np.bincount(op[valid], minlength=9000)
+    giant_obs = int(counts[counts > 64].sum())
+    assert st["n_giant_obs"] == giant_obs and giant_obs >= 200
+    assert st["n_obs"] == int(valid.sum()) - giant_obs
+    assert st["n_entries"] >= st["n_obs"] and st["n_seg"] * 4 >= st["n_obs"]
+    assert 1.0 <= st["cam_mult"] <= 8.0 and st["pt_mult"] >= 1.0
