@@ -174,6 +174,9 @@ struct miba_handle_s {
   int pcg_nb = 1, red_nb = 1, red_cpb = 4;         // grids of the fused PCG kernels / camera reduction
   int n_cu = 1, dev_share = 1;                    // compute units of the device; ranks of this process that share it
   int tail_nb = 1, tail_n_vw = 0;                 // grid of pcg_tail: resident as a whole (it holds grid barriers); wave records
+  int tail_occ = 1;                               // workgroups of pcg_tail one compute unit can hold (occupancy query at create)
+  int tail_split = 0;                             // 1: the PCG tail runs without grid barriers (three launches): MIBA_TAIL_SPLIT=1, or a barrier timed out once
+  long long tail_timeout = 200000000ll;           // barrier patience in 100 MHz ticks (MIBA_TAIL_TIMEOUT_TICKS: tests)
   int32_t* d_tail_rec = nullptr;                  // [tail_n_vw][kTailRec] camera ranges of the tail's waves
   long long* d_tail_dbg = nullptr;                // MIBA_TAIL_DEBUG=1: phase time stamps of the tail's workgroups
   unsigned* d_bar = nullptr;                      // barrier counter of pcg_tail
@@ -701,14 +704,8 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
   A.part_q = part_q; A.part_rho0 = part_rho[0]; A.part_rho1 = part_rho[1];
   A.q_tol = q_tol; A.min_it = min_it; A.max_it = max_it;
   A.bar = h->d_bar;
+  A.bar_timeout = h->tail_timeout;
   A.dbg = h->d_tail_dbg;
-  HIPCHK(h, hipMemsetAsync(h->d_bar, 0, kBarWords * sizeof(unsigned), h->st));
-  hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
-                     part_nb, part_rho[1]);
-  hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_nb, nb, h->d_ctl);
-  hipLaunchKernelGGL(pcg_chkdir, dim3(nb), dim3(256), 0, h->st, 1, n, h->d_pz, h->d_pp, h->d_ctl, part_rho[0], part_rho[1], nb, A.part_pq,
-                     A.n_pq, part_q, q_tol, min_it, max_it);
-  HIPCHK(h, hipGetLastError());
   if (check_every < 1) check_every = 1;
   // camera-side sum (phase A of the tail as a launch of its own: this rank's slab rows) and all-reduce (several ranks)
   auto reduce_step = [&](bool on_x, int j, bool sample) -> int {
@@ -722,40 +719,76 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
     HIPCHK(h, hipGetLastError());
     return allreduce(h, h->d_pq, n + (on_x ? 0 : (size_t)nb), ncclSum);
   };
-  for (int j = 1;; ++j) {
-    Ctl* cur = h->d_ctl + ((j - 1) & 1);   // C_{j-1}: state after the j-1 iterations tested so far
-    const int it = j - 1;
-    // Host poll: the control block is copied out and marked by an event, iteration j is enqueued behind it, and only
-    // then does the host wait for the copy: the device works on iteration j while the host looks at C_{j-1}, instead
-    // of idling for a host round trip (34 us per poll at Final-13682).  If C_{j-1} says done, iteration j's kernels
-    // return at once, like every launch enqueued past convergence.
-    const bool poll = it >= 1 && (it % check_every == 0 || it >= max_it);
-    if (poll) {
-      HIPCHK(h, hipMemcpyAsync(h->h_ctl, cur, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
-      HIPCHK(h, hipEventRecord(h->ev_poll, h->st));
-    }
-    const bool sample = (j - 1) % h->time_every == 0;
-    const bool reset = (j % 10 == 0);  // residual_reset_period
-    A.j = j;
-    int rc = MIBA_OK;
-    mf_matvec_tiles(h, h->d_pp, cur, j, sample);
-    if (multi && (rc = reduce_step(false, j, sample))) return rc;
-    if (!reset) {
-      Timed t(h, multi ? -1 : MIBA_K_CAM_REDUCE, j, sample && !multi);
-      launch_tail<0>(h, A, !multi);
-    } else {
-      launch_tail<1>(h, A, !multi);
-      HIPCHK(h, hipGetLastError());
-      mf_matvec_tiles(h, h->d_px, cur, j, sample);   // q = S p is dead once x is updated: reuse it for S x
-      if (multi && (rc = reduce_step(true, j, false))) return rc;
-      launch_tail<2>(h, A, !multi);
-    }
+  // The tail after phase A.  One launch with two grid barriers when the device is this solver's own; without barriers
+  // (tail_split: MIBA_TAIL_SPLIT=1, or after a barrier of this handle has timed out once) phase B and phase C are launches of
+  // their own, which any amount of foreign work on the device can delay but not deadlock.
+  auto tail_rest = [&](auto mode_tag, bool reduce) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    if (!h->tail_split || MODE == 1) { launch_tail<MODE>(h, A, reduce); return; }
+    TailArgs B = A;
+    B.split = 1;
+    launch_tail<MODE>(h, B, false);
+    B.split = 2;
+    launch_tail<MODE>(h, B, false);
+  };
+  for (int attempt = 0;; ++attempt) {
+    const bool split = h->tail_split != 0;
+    const bool own_reduce = multi || split;   // phase A as its own launch
+    HIPCHK(h, hipMemsetAsync(h->d_bar, 0, kBarWords * sizeof(unsigned), h->st));
+    hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
+                       part_nb, part_rho[1]);
+    hipLaunchKernelGGL(pcg_start2, dim3(1), dim3(256), 0, h->st, part_nb, nb, h->d_ctl);
+    hipLaunchKernelGGL(pcg_chkdir, dim3(nb), dim3(256), 0, h->st, 1, n, h->d_pz, h->d_pp, h->d_ctl, part_rho[0], part_rho[1], nb, A.part_pq,
+                       A.n_pq, part_q, q_tol, min_it, max_it);
     HIPCHK(h, hipGetLastError());
-    if (poll) {
-      HIPCHK(h, hipEventSynchronize(h->ev_poll));
-      if (h->h_ctl->done) break;
-      if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
+    for (int j = 1;; ++j) {
+      Ctl* cur = h->d_ctl + ((j - 1) & 1);   // C_{j-1}: state after the j-1 iterations tested so far
+      const int it = j - 1;
+      // Host poll: the control block is copied out and marked by an event, iteration j is enqueued behind it, and only
+      // then does the host wait for the copy: the device works on iteration j while the host looks at C_{j-1}, instead
+      // of idling for a host round trip (34 us per poll at Final-13682).  If C_{j-1} says done, iteration j's kernels
+      // return at once, like every launch enqueued past convergence.
+      const bool poll = it >= 1 && (it % check_every == 0 || it >= max_it);
+      if (poll) {
+        HIPCHK(h, hipMemcpyAsync(h->h_ctl, cur, sizeof(Ctl), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(h, hipEventRecord(h->ev_poll, h->st));
+      }
+      const bool sample = (j - 1) % h->time_every == 0;
+      const bool reset = (j % 10 == 0);  // residual_reset_period
+      A.j = j;
+      int rc = MIBA_OK;
+      mf_matvec_tiles(h, h->d_pp, cur, j, sample);
+      if (own_reduce && (rc = reduce_step(false, j, sample))) return rc;
+      if (!reset) {
+        Timed t(h, own_reduce ? -1 : MIBA_K_CAM_REDUCE, j, sample && !own_reduce);
+        tail_rest(std::integral_constant<int, 0>(), !own_reduce);
+      } else {
+        tail_rest(std::integral_constant<int, 1>(), !own_reduce);
+        HIPCHK(h, hipGetLastError());
+        mf_matvec_tiles(h, h->d_px, cur, j, sample);   // q = S p is dead once x is updated: reuse it for S x
+        if (own_reduce && (rc = reduce_step(true, j, false))) return rc;
+        tail_rest(std::integral_constant<int, 2>(), !own_reduce);
+      }
+      HIPCHK(h, hipGetLastError());
+      if (poll) {
+        HIPCHK(h, hipEventSynchronize(h->ev_poll));
+        if (h->h_ctl->done) break;
+        if (it >= max_it + check_every) return fail(h, MIBA_ERR_INVALID, "PCG did not report termination");
+      }
     }
+    if (!(h->h_ctl->fail & 16)) break;
+    // A grid barrier of the tail kernel was not reached in time: something else holds compute units of this device, so the
+    // tail's grid was not resident as a whole.  From here on this handle uses the form without barriers; the solve starts over
+    // (x0 = 0, the control block is rebuilt by pcg_start, which keeps the factorisation flags).
+    if (attempt > 0 || split)
+      return fail(h, MIBA_ERR_HIP, "the PCG tail kernel's grid barrier timed out (its grid was not resident as a whole)");
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    classify_pcg_events(h, 0);
+    h->tail_split = 1;
+    if (h->cfg.log_level > 0) fprintf(stderr, "[miba] a grid barrier of the PCG tail timed out: this handle now runs the tail without barriers\n");
+    const int32_t flags = h->h_ctl->fail & ~16;
+    HIPCHK(h, hipMemcpyAsync(&h->d_ctl->fail, &flags, sizeof(int32_t), hipMemcpyHostToDevice, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
   }
   if (A.dbg) {   // phase time stamps of the last tail launch that went through all phases: spread over the workgroups
     std::vector<long long> st(8 * (size_t)h->tail_nb);
@@ -770,7 +803,6 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
       fprintf(stderr, "%s %lld..%lld%s", nm[n], lo, hi, n < 5 ? ", " : "\n");
     }
   }
-  if (h->h_ctl->fail & 16) return fail(h, MIBA_ERR_HIP, "the PCG tail kernel's grid barrier timed out (its grid was not resident as a whole)");
   *n_it = h->h_ctl->n_it;
   *status = h->h_ctl->status;
   classify_pcg_events(h, *n_it);
@@ -1549,9 +1581,17 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
   if (e == hipSuccess) e = static_scratch_for(dev, &h->static_scratch);   // device `dev` is current here
   if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev);
   if (const char* te = getenv("MIBA_TIME_EVERY")) { const int v = atoi(te); if (v >= 1) h->time_every = v; }
+  // the PCG tail kernel meets at grid barriers: its grid may not exceed what the device holds at once
+  if (e == hipSuccess) {
+    int occ = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pcg_tail<0, true>, kTailThreads, 0);
+    h->tail_occ = std::max(1, occ);
+  }
+  if (const char* te = getenv("MIBA_TAIL_SPLIT")) h->tail_split = te[0] == '1';
+  if (const char* te = getenv("MIBA_TAIL_TIMEOUT_TICKS")) { const long long v = atoll(te); if (v >= 1) h->tail_timeout = v; }
   if (e != hipSuccess) {
     int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
-    delete h;
+    miba_destroy(h);   // frees what has been created so far (stream, pinned blocks, event)
     return rc;
   }
   const char* force = getenv("MIBA_FORCE_RCCL");
@@ -1559,12 +1599,13 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
     ncclUniqueId id;
     if (cfg->comm_unique_id) memcpy(&id, cfg->comm_unique_id, sizeof(id));
     else if (cfg->world_size == 1) {
-      if (ncclGetUniqueId(&id) != ncclSuccess) { delete h; return fail(nullptr, MIBA_ERR_RCCL, "ncclGetUniqueId failed"); }
-    } else { delete h; return fail(nullptr, MIBA_ERR_INVALID, "world_size > 1 needs comm_unique_id"); }
+      if (ncclGetUniqueId(&id) != ncclSuccess) { miba_destroy(h); return fail(nullptr, MIBA_ERR_RCCL, "ncclGetUniqueId failed"); }
+    } else { miba_destroy(h); return fail(nullptr, MIBA_ERR_INVALID, "world_size > 1 needs comm_unique_id"); }
     ncclResult_t r = ncclCommInitRank(&h->comm, cfg->world_size, id, cfg->rank);
     if (r != ncclSuccess) {
       int rc = fail(nullptr, MIBA_ERR_RCCL, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
-      delete h;
+      h->comm = nullptr;
+      miba_destroy(h);
       return rc;
     }
   }
@@ -1635,6 +1676,21 @@ int miba_create_multi(const int32_t* device_ids, int32_t n_devices, int32_t log_
     else { destroy_group(G); delete g; return fail(nullptr, MIBA_ERR_INVALID, "MIBA_ALLREDUCE must be rccl, peer or host"); }
   }
   if (G->mode == kCommRccl && repeated) { destroy_group(G); delete g; return fail(nullptr, MIBA_ERR_INVALID, "RCCL cannot put two ranks on one device"); }
+  {
+    // The peer kernel of a rank spins until the other ranks' kernels have arrived.  Ranks on ONE device launch on streams that
+    // share the process's four hardware queues: with more than three of them a rank's kernel can sit in a queue behind a
+    // spinning one and never start, and every all-reduce would run into its time limit.  Such groups use the host transport.
+    int max_share = 0;
+    for (int r = 0; r < n_devices; ++r) {
+      int share = 0;
+      for (int q = 0; q < n_devices; ++q) share += dev[q] == dev[r];
+      max_share = std::max(max_share, share);
+    }
+    if (G->mode == kCommPeer && max_share > kPeerMaxRanksPerDevice) {
+      if (log_level > 0) fprintf(stderr, "[miba] MIBA_ALLREDUCE=peer with %d ranks on one device (limit %d): using the host transport\n", max_share, kPeerMaxRanksPerDevice);
+      G->mode = kCommHost;
+    }
+  }
   int rc = MIBA_OK;
   for (int r = 0; r < n_devices && rc == MIBA_OK; ++r) {
     rc = create_rank(dev[r], r, n_devices, log_level, &G->sub[r]);
@@ -1865,7 +1921,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   h->red_nb = nblk(p->n_cam, h->red_cpb);
   // the tail kernel of a PCG iteration holds grid barriers: its grid must be resident as a whole.  One workgroup (kTailThreads) per
   // compute unit at most, one per sixteen cameras on a small problem; ranks of this process that share the device share its compute units.
-  h->tail_nb = std::max(1, std::min(nblk(p->n_cam, 16), h->n_cu / std::max(1, h->dev_share)));
+  h->tail_nb = std::max(1, std::min(nblk(p->n_cam, 16), std::min(h->n_cu, h->n_cu * h->tail_occ) / std::max(1, h->dev_share)));
   h->t0 = P.shard_tile[h->cfg.rank];
   h->t1 = P.shard_tile[h->cfg.rank + 1];
   h->n_tiles = h->t1 - h->t0;

@@ -20,6 +20,7 @@
 namespace miba {
 
 constexpr int kMaxRanks = 8;
+constexpr int kPeerMaxRanksPerDevice = 3;          // ranks of one group that may share a device under the peer transport (see miba_create_multi)
 constexpr int kPeerBlocks = 32;                  // workgroups per rank kernel (all resident; they wait on each other)
 constexpr size_t kPeerChunk = (size_t)1 << 20;   // doubles per staging half (8 MiB): larger buffers go in pieces
 

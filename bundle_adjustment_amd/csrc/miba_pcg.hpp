@@ -68,7 +68,7 @@ __device__ __forceinline__ double tail_sum_partials(const double* part, int n, d
 // fence stays as the compiler barrier.  Returns false when the others did not arrive in time.
 constexpr int kBarGroup = 16;
 constexpr int kBarStride = 32;   // unsigneds between counters (128 bytes)
-__device__ __forceinline__ bool tail_grid_barrier(unsigned* bar, unsigned n_blocks, int* s_ok) {
+__device__ __forceinline__ bool tail_grid_barrier(unsigned* bar, unsigned n_blocks, int* s_ok, long long timeout_ticks) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -83,7 +83,7 @@ __device__ __forceinline__ bool tail_grid_barrier(unsigned* bar, unsigned n_bloc
     int ok = 1;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > 200000000ll) { ok = 0; break; }   // 2 s of the 100 MHz counter
+      if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }   // (2 s of the 100 MHz counter by default)
     }
     *s_ok = ok;
   }
@@ -146,6 +146,10 @@ struct TailArgs {
   double q_tol; int min_it, max_it;
   int a_on_x;          // MODE 3: the product's input is x (residual refresh), not p
   unsigned* bar;       // barrier counters
+  long long bar_timeout;   // ticks of the 100 MHz counter a barrier waits before it gives up (2 s; tests shorten it)
+  int split;           // 0: one launch.  The form WITHOUT grid barriers (a device shared with other work, where the grid may not be
+                       // resident as a whole): phase A as pcg_tail<3>, then 1: this launch ends after phase B, 2: this launch is
+                       // phase C (scalars recomputed from the partial sums, vectors from memory)
   long long* dbg;      // MIBA_TAIL_DEBUG: [workgroup][8] time stamps of the phases (100 MHz counter), else null
 };
 #define TAIL_STAMP(n) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + n] = wall_clock64(); } while (0)
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   // wave records vw0, vw0 + n_waves, ...: consecutive records go to different workgroups, so that every workgroup has work
   // when there are fewer records than waves
   const int vw0 = wv * nb + blockIdx.x, n_waves = nb * kTailWaves;
-  const bool single = a.n_vw <= n_waves;   // one round: values are carried in registers
+  const bool single = a.n_vw <= n_waves && a.split == 0;   // one round: values are carried in registers
   // the first record is fetched together with the control block (one trip to memory instead of two)
   const int rec_first = (vw0 < a.n_vw) ? a.wave_rec[(size_t)kTailRec * vw0 + min(lane, kTailRec - 1)] : 0;
   Ctl c = a.ctl[(j - 1) & 1];   // C_{j-1}
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
       const double s = tail_block_sum(xy, s32);
       if (tid == 0) tail_put(a.part_pq + blockIdx.x, s);
       TAIL_STAMP(1);
-      if (!tail_grid_barrier(a.bar, nb, &s_ok)) {
+      if (!tail_grid_barrier(a.bar, nb, &s_ok, a.bar_timeout)) {
         if (writer) tail_timed_out(a.ctl);
         return;
       }
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   const double alpha = rho / pq;
   const bool alpha_bad = !pq_bad && isinf(alpha);
   TAIL_STAMP(3);
-  if (!pq_bad && !alpha_bad) {
+  if (!pq_bad && !alpha_bad && a.split != 2) {
     double a_q = 0.0, a_rho = 0.0;
     for (int vw = vw0; vw < a.n_vw; vw += n_waves) {
       int cam0 = cam0_1, ncw = ncw_1;
@@ -369,9 +373,9 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
       }
     }
   }
-  if (MODE == 1) return;
+  if (MODE == 1 || a.split == 1) return;
   TAIL_STAMP(4);
-  if (!tail_grid_barrier(a.bar, nb, &s_ok)) {
+  if (a.split == 0 && !tail_grid_barrier(a.bar, nb, &s_ok, a.bar_timeout)) {
     if (writer) tail_timed_out(a.ctl);
     return;
   }

@@ -611,7 +611,7 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
     int next_t[kMaxCamSlots][16];
     int rd_cnt[32][32], at_cnt[64][16];
     const bool no_color = getenv("MIBA_CM_COLOR") && getenv("MIBA_CM_COLOR")[0] == '0';   // (diagnostic: slots in point order)
-    std::vector<int32_t> place;
+    std::vector<int32_t> place, porder, poff;
     for (int64_t ti = ta; ti < tb; ++ti) {
       const Tile& T = tiles[(size_t)ti];
       if (T.giant || T.ngrp == 0) continue;
@@ -653,9 +653,15 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
         // beyond the row's last segment); with more than sixteen observations the least used class.
         for (int c = 0; c < kMaxCamSlots; ++c)
           for (int k = 0; k < 16; ++k) next_t[c][k] = 0;
-        // (lane | step << 8) of every observation, points in order
-        place.clear();
-        for (int32_t r = p; r < q; ++r) {
+        // (lane | step << 8 | camera slot << 16) of every observation, points in order; the longest points choose first (they
+        // need the most distinct classes)
+        place.resize((size_t)(seg_off[kMaxCamSlots] * kCmSeg));
+        porder.resize((size_t)(q - p));
+        poff.resize((size_t)(q - p) + 1);
+        poff[0] = 0;
+        for (int32_t r = p; r < q; ++r) { porder[(size_t)(r - p)] = r; poff[(size_t)(r - p) + 1] = poff[(size_t)(r - p)] + pt_count_local[r]; }
+        std::stable_sort(porder.begin(), porder.end(), [&](int32_t x, int32_t y) { return pt_count_local[x] > pt_count_local[y]; });
+        for (const int32_t r : porder) {
           const int32_t s0 = pt_first_local[r], n = pt_count_local[r];
           int used[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           for (int32_t s = s0; s < s0 + n; ++s) {
@@ -670,7 +676,7 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
             }
             const int pos = ((best - shift) & 15) + 16 * next_t[cs][best]++;
             ++used[best];
-            place.push_back(lane_of(seg_off[cs] + pos / kCmSeg) | ((pos % kCmSeg) << 8) | (cs << 16));
+            place[(size_t)poff[(size_t)(r - p)] + (size_t)(s - s0)] = lane_of(seg_off[cs] + pos / kCmSeg) | ((pos % kCmSeg) << 8) | (cs << 16);
             ++Q.n_valid;
           }
         }
@@ -686,9 +692,9 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
           for (int c = 0; c < 32; ++c) free_per_color[c] = 0;
           const size_t sbase = Q.slot.size();
           Q.slot.resize(sbase + kCmLanes, 0);
-          size_t o = 0;
-          for (int32_t r = p; r < q; ++r) {
+          for (const int32_t r : porder) {
             const int32_t n = pt_count_local[r];
+            const size_t o = (size_t)poff[(size_t)(r - p)];
             int best = -1, best_cost = 1 << 30;
             for (int cc = 0; cc < 32; ++cc) {
               const int c = (cc + (int)(r - p)) & 31;
@@ -710,7 +716,6 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
               const uint64_t e = (uint64_t)slot | ((uint64_t)cs << 8) | 0x8000u;
               out[lane] |= e << (16 * step);
             }
-            o += (size_t)n;
           }
         }
         for (int c = 0; c < kMaxCamSlots; ++c) {

@@ -282,8 +282,9 @@ int miba_get_reduced_system(miba_handle h, double* S_out);
 int miba_dense_spd_solve(miba_handle h, int32_t n, const double* A, const double* b, double* x, int32_t* status);
 
 /* miba_dense_spd_solve_static: NO COUNTERPART IN THE REFERENCE.  The same factorisation as miba_dense_spd_solve for
- * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc.  It calls no hipMalloc / hipFree / allocating routine: the padded matrix, the diagonal-block
+ * callers that cannot allocate device memory: tight serving loops, harnesses that forbid hipMalloc, the set-up phase
+ * around a HIP graph capture (NOT inside one: the work runs on the handle's own stream and the call synchronises it, so
+ * nothing of it would be captured).  It calls no hipMalloc / hipFree / allocating routine: the padded matrix, the diagonal-block
  * factors and the pivot flag live in a file-scope static __device__ array of the library (9.4 MB, held by every GPU
  * the library runs on until the process ends), whose device address is resolved once per device at miba_create.
  * All four pointers are DEVICE pointers on the handle's GPU: A (n x n row-major, lower triangle read), b (n),

@@ -75,6 +75,48 @@ def test_dubrovnik_linear_step_matches_oracle(oracle):
     assert abs(out["model_cost_change"] - ref["model_cost_change"]) <= 1e-9 * abs(ref["model_cost_change"])
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0]])
+def test_dubrovnik_point_sharded_matches_oracle(oracle, devices):
+    """BASELINE.json configs[2] as it is stated: Dubrovnik-356 point-sharded over 2 and 4 ranks (one handle, every rank on
+    device 0: the box has one GPU; the ranks, their shards and their reductions are the multi-GPU code), against the ORACLE
+    directly: reduced right-hand side and S v to 1e-10, the same PCG iteration count, the step to 1e-7."""
+    pr, cams0, pts0 = _problem("dubrovnik-356")
+    probe = np.random.default_rng(9).normal(size=(pr["n_cam"], 9))
+    s = miba.Solver(devices=devices)
+    s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    out = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR), probe=probe)
+    s.close()
+    sc, sp = oracle.jacobi_scale(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    ref = oracle.linear_step(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"], 1e4, sc, sp,
+                             oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, num_threads=8), probe=probe)
+    assert rel(out["rhs"], ref["rhs"]) <= 1e-10
+    assert rel(out["Sv"], ref["Sv"]) <= 1e-10
+    assert out["n_cg"] == ref["n_cg"]
+    assert rel(out["y_cam"], ref["y_cam"]) <= 1e-7 and rel(out["y_pt"], ref["y_pt"]) <= 1e-7
+    assert abs(out["model_cost_change"] - ref["model_cost_change"]) <= 1e-9 * abs(ref["model_cost_change"])
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_sharded_lm_iterations_match_oracle(oracle, devices):
+    """A multi-rank LM run against the oracle's per-iteration table (trafalgar-257: cost to 1e-9, the same accept / reject
+    decisions and PCG iteration counts), so that the sharded path has an oracle check of its own and does not lean on the
+    one-rank run alone."""
+    pr, cams0, pts0 = _problem("trafalgar-257")
+    kw = dict(max_num_iterations=5, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
+    s = miba.Solver(devices=devices)
+    s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    its, summ = s.solve(miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, **kw))
+    s.close()
+    _, _, oits, osumm = oracle.solve(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"],
+                                     oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, num_threads=8, **kw))
+    assert len(its) == len(oits)
+    for a, b in zip(its, oits):
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(b["cost"]), (a, b)
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert a["linear_solver_iterations"] == b["linear_solver_iterations"]
+    assert abs(summ["final_cost"] - osumm["final_cost"]) <= 1e-6 * osumm["final_cost"]
+
+
 def test_final_13682_properties():
     """configs[1] at full size.  S is symmetric positive definite and linear; the LM cost sequence is monotone over
     accepted steps, starts at the cost miba_evaluate reports, and the state handed back has the reported final

@@ -166,3 +166,76 @@ def test_run_that_ends_on_function_tolerance_has_ceres_record_count(oracle):
     assert its[-1]["iteration"] == len(its) - 1
     assert summ["num_iterations"] == len(its) - 1 == summ["num_successful_steps"] + summ["num_unsuccessful_steps"]
     assert summ["num_successful_steps"] == osumm["num_successful"] and summ["num_unsuccessful_steps"] == osumm["num_unsuccessful"]
+
+
+def _lm_table(pr, cams0, pts0, iters=6):
+    s = miba.Solver(device_id=0)
+    s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+    its, summ = s.solve(miba.default_options(max_num_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0,
+                                             parameter_tolerance=0.0))
+    s.close()
+    return [(r["step_is_successful"], r["linear_solver_iterations"]) for r in its], [r["cost"] for r in its], summ
+
+
+def _same_run(a, b):
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y in zip(a[1], b[1]):
+        assert abs(x - y) <= 1e-9 * abs(y)
+
+
+@pytest.fixture(scope="module")
+def tail_problem():
+    pr = synth.make_problem(300, 20000, 120000, seed=31)
+    cams0, pts0 = synth.perturb(pr, 0.005, 0.05, seed=32)
+    return pr, cams0, pts0
+
+
+def test_pcg_tail_without_grid_barriers(tail_problem, monkeypatch):
+    """MIBA_TAIL_SPLIT=1: phase A, phase B and phase C of the PCG tail as three launches, no grid barrier (the form for a device
+    that this solver does not have to itself): the same LM table as the one-launch tail."""
+    pr, cams0, pts0 = tail_problem
+    ref = _lm_table(pr, cams0, pts0)
+    monkeypatch.setenv("MIBA_TAIL_SPLIT", "1")
+    _same_run(_lm_table(pr, cams0, pts0), ref)
+
+
+def test_pcg_tail_barrier_timeout_falls_back(tail_problem, monkeypatch):
+    """A grid barrier that times out (here: a patience of one tick of the 100 MHz counter, which no barrier of several
+    workgroups meets) no longer ends the solve with MIBA_ERR_HIP: the handle switches to the tail without barriers, the
+    linear solve starts over, and the LM table is the one of the undisturbed run."""
+    pr, cams0, pts0 = tail_problem
+    ref = _lm_table(pr, cams0, pts0)
+    monkeypatch.setenv("MIBA_TAIL_TIMEOUT_TICKS", "1")
+    _same_run(_lm_table(pr, cams0, pts0), ref)
+
+
+def test_solve_while_another_stream_keeps_the_device_busy(tail_problem):
+    """The PCG tail's one-launch form needs its grid resident as a whole.  A second handle of the same process (its own stream)
+    that keeps the compute units busy with back-to-back products of a two-million-observation problem delays it but must not
+    break it: same LM table, no error (a barrier that did time out would switch the handle to the tail without barriers)."""
+    import threading
+    pr, cams0, pts0 = tail_problem
+    ref = _lm_table(pr, cams0, pts0)
+    big = synth.make_problem(2000, 300000, 2000000, seed=77)
+    bc, bp = synth.perturb(big, 0.002, 0.03, seed=78)
+    hog = miba.Solver(device_id=0)
+    hog.set_problem(bc, bp, big["obs_cam"], big["obs_pt"], big["obs_xy"])
+    probe = np.random.default_rng(1).normal(size=(big["n_cam"], 9))
+    hog.linear_step(1e4, miba.default_options(max_linear_solver_iterations=1), probe=probe)
+    stop = threading.Event()
+    busy = []
+
+    def run_hog():
+        while not stop.is_set():
+            busy.append(hog.time_matvec(probe, 50))
+
+    t = threading.Thread(target=run_hog, daemon=True)
+    t.start()
+    try:
+        got = _lm_table(pr, cams0, pts0)
+    finally:
+        stop.set()
+        t.join(timeout=120)
+        hog.close()
+    assert busy, "the second handle never ran"
+    _same_run(got, ref)
