@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -77,6 +78,8 @@ struct RankGroup {
   std::vector<PeerSignals*> psig;
   // decisions of rank 0 handed to the other ranks once per LM iteration (callback result, time limit)
   std::atomic<int> ctl_stop[2];
+  // the solve in progress runs its iteration callback on a worker thread, from state snapshots (options.async_callbacks)
+  std::atomic<int> async_cb{0};
   // spin barrier of the rank threads; fails (instead of hanging) when a rank has left with an error
   int barrier() {
     const int g = bar_gen.load(std::memory_order_acquire);
@@ -185,6 +188,7 @@ struct miba_handle_s {
   Loss loss = {kLossNone, 1.0};                   // robust loss of the current solve (options.loss_type / loss_scale)
   double* d_omega = nullptr;                      // [n_slots] loss weights rho' of the current linearisation (loss only)
   double *d_X = nullptr, *d_Xc = nullptr, *d_sp = nullptr, *d_J = nullptr;
+  double* d_gather = nullptr;   // one process per GPU: all points of the problem, for miba_get_state's gather (allocated on first use)
   double *d_gp = nullptr, *d_dgp = nullptr, *d_yp = nullptr;
   double *d_slab9 = nullptr, *d_camacc = nullptr, *d_Minv = nullptr, *d_Dc2 = nullptr, *d_rhs = nullptr;
   double *d_px = nullptr, *d_pr = nullptr, *d_pz = nullptr, *d_pp = nullptr, *d_pq = nullptr, *d_probe = nullptr;
@@ -210,6 +214,19 @@ struct miba_handle_s {
   Ctl* d_ctl = nullptr;
   std::vector<void*> allocs;
 
+  // State snapshots for iteration callbacks that run beside the solver (options.async_callbacks): after every iteration that
+  // changed the state, the cameras and this shard's points are copied on a second stream into one of two pinned buffers;
+  // miba_get_state called from inside such a callback reads the snapshot (snap_read >= 0) and touches no device.
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_state = nullptr, ev_snap[2] = {nullptr, nullptr};
+  double* snap_cam[2] = {nullptr, nullptr};
+  double* snap_X[2] = {nullptr, nullptr};
+  size_t snap_cam_n = 0, snap_X_n = 0;
+  int snap_last = -1;                       // buffer of the newest snapshot
+  bool snap_recorded[2] = {false, false};   // ev_snap[b] has been recorded at least once
+  std::atomic<int> snap_seq{-1};            // newest iteration whose snapshot has been enqueued (published for the callback worker)
+  int snap_buf_of[2] = {-1, -1};            // buffer that holds the state of iteration k, at [k & 1]
+  int snap_read = -1;                       // >= 0 while a callback runs on the worker: the buffer miba_get_state reads
   // host pinned
   double* h_stage = nullptr; size_t h_stage_n = 0;   // staging for miba_get_state (points), grown on demand
   double* h_scal = nullptr;   // 2*S_COUNT
@@ -1469,6 +1486,60 @@ int state_norm2(miba_handle h, double* out) {
   return MIBA_OK;
 }
 
+// device -> pinned host memory by plain stores (few workgroups: the copy shares the device with the solver's kernels)
+__global__ __launch_bounds__(256) void k_copy_out(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// options.async_callbacks: copy the current state (cameras, this shard's points) into a pinned snapshot buffer on the second
+// stream, behind everything the solver stream has enqueued so far; the solver stream does not wait.  Publishes the buffer for
+// iteration `iteration` (snap_buf_of, snap_seq).  changed = false: the state is the one of the iteration before, no copy.
+int snapshot_enqueue(miba_handle h, int iteration, bool changed) {
+  if (changed || h->snap_last < 0) {
+    if (!h->st2) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
+      for (int b = 0; b < 2; ++b) HIPCHK(h, hipEventCreateWithFlags(&h->ev_snap[b], hipEventDisableTiming));
+    }
+    const size_t nc = 9 * (size_t)std::max(1, h->n_cam), np = 3 * (size_t)std::max(1, h->n_pt);
+    if (h->snap_cam_n < nc || h->snap_X_n < np) {
+      for (int b = 0; b < 2; ++b) {
+        if (h->snap_cam[b]) (void)hipHostFree(h->snap_cam[b]);
+        if (h->snap_X[b]) (void)hipHostFree(h->snap_X[b]);
+        h->snap_cam[b] = h->snap_X[b] = nullptr;
+      }
+      h->snap_cam_n = h->snap_X_n = 0;
+      for (int b = 0; b < 2; ++b) {
+        HIPCHK(h, hipHostMalloc((void**)&h->snap_cam[b], nc * sizeof(double)));
+        HIPCHK(h, hipHostMalloc((void**)&h->snap_X[b], np * sizeof(double)));
+      }
+      h->snap_cam_n = nc; h->snap_X_n = np;
+    }
+    const int b = h->snap_last < 0 ? 0 : h->snap_last ^ 1;
+    HIPCHK(h, hipEventRecord(h->ev_state, h->st));
+    HIPCHK(h, hipStreamWaitEvent(h->st2, h->ev_state, 0));
+    // by a kernel that stores into the pinned buffers, not by the copy engine: the solver stream's own small device-to-host
+    // copies (the PCG control block the host polls) would queue behind a 107 MB transfer on the engine and stall the PCG
+    hipLaunchKernelGGL(k_copy_out, dim3(8), dim3(256), 0, h->st2, h->d_cam, h->snap_cam[b], 9 * (size_t)h->n_cam);
+    if (h->n_pt) hipLaunchKernelGGL(k_copy_out, dim3(64), dim3(256), 0, h->st2, h->d_X, h->snap_X[b], 3 * (size_t)h->n_pt);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_snap[b], h->st2));
+    h->snap_recorded[b] = true;
+    h->snap_last = b;
+  }
+  h->snap_buf_of[iteration & 1] = h->snap_last;
+  h->snap_seq.store(iteration, std::memory_order_release);
+  return MIBA_OK;
+}
+
+// the candidate buffers are about to be overwritten: a snapshot copy that still reads one of them (it was the state two
+// iterations ago) must have finished.  Stream-ordered, no host wait.
+int snapshot_guard(miba_handle h) {
+  for (int b = 0; b < 2; ++b)
+    if (h->snap_recorded[b]) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_snap[b], 0));
+  return MIBA_OK;
+}
+
 int read_scalars(miba_handle h) {
   HIPCHK(h, hipMemcpyAsync(h->h_scal, h->d_sum, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipMemcpyAsync(h->h_scal + S_COUNT, h->d_max, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->st));
@@ -1539,7 +1610,7 @@ void miba_default_options(miba_options* o) {
   o->eta_exact = 1e-12;
   o->max_solver_time_in_seconds = 1e9;
   o->loss_type = MIBA_LOSS_NONE;
-  o->reserved = 0;
+  o->async_callbacks = 0;
   o->loss_scale = 1.0;
 }
 
@@ -1758,6 +1829,13 @@ int miba_destroy(miba_handle h) {
   if (h->ev_poll) (void)hipEventDestroy(h->ev_poll);
   if (h->comm) (void)ncclCommDestroy(h->comm);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
+  for (int b = 0; b < 2; ++b) {
+    if (h->snap_cam[b]) (void)hipHostFree(h->snap_cam[b]);
+    if (h->snap_X[b]) (void)hipHostFree(h->snap_X[b]);
+    if (h->ev_snap[b]) (void)hipEventDestroy(h->ev_snap[b]);
+  }
+  if (h->ev_state) (void)hipEventDestroy(h->ev_state);
+  if (h->st2) { (void)hipStreamSynchronize(h->st2); (void)hipStreamDestroy(h->st2); }
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   if (h->st) (void)hipStreamDestroy(h->st);
@@ -2113,6 +2191,7 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   h->d_dseg = nullptr; h->d_dpts = nullptr; h->n_dseg = 0; h->dense_planned = false; h->dense_plan_tried = false; h->d_camacc2 = nullptr;
   h->sparse_state = 0; h->d_sp_tiles = nullptr;
   h->d_omega = nullptr;
+  h->d_gather = nullptr;
   ALLOC(h->d_gp, 3 * np); ALLOC(h->d_dgp, 3 * np); ALLOC(h->d_yp, 3 * np);
   // the 64-wide per-(tile, camera) slab is only used by the stored-Jacobian K2 and the one-pass K2-mf
   ALLOC(h->d_slab9, 9 * (size_t)n_rows);
@@ -2329,18 +2408,36 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
     return MIBA_OK;
   }
   if (!h || !h->has_problem) return fail(h, MIBA_ERR_INVALID, "set_problem has not been called");
-  HIPCHK(h, hipSetDevice(h->device));
-  std::vector<double> cam(9 * (size_t)h->n_cam);
-  HIPCHK(h, hipMemcpyAsync(cam.data(), h->d_cam, cam.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
+  // called from inside an iteration callback that runs beside the solver (options.async_callbacks): the state of that
+  // iteration is in a pinned snapshot; no device call is made (the solver thread is using the device).  With one process per
+  // GPU the snapshot holds this rank's points, and only those are written.
+  const int snap = h->snap_read;
+  std::vector<double> cam(snap >= 0 ? (size_t)0 : 9 * (size_t)h->n_cam);
+  const double* cam_src = snap >= 0 ? h->snap_cam[snap] : cam.data();
+  if (snap < 0) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(cam.data(), h->d_cam, cam.size() * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipStreamSynchronize(h->st));
+  }
   for (int c = 0; c < h->n_cam; ++c) {
     if (!h->plan_ref().cam_active[c]) continue;   // blocks that are not in the problem stay untouched
-    const double* o = cam.data() + 9 * (size_t)c;
+    const double* o = cam_src + 9 * (size_t)c;
     if (R) { R[3 * c] = o[0]; R[3 * c + 1] = o[1]; R[3 * c + 2] = o[2]; }
     if (T) { T[3 * c] = o[3]; T[3 * c + 1] = o[4]; T[3 * c + 2] = o[5]; }
     if (K && h->cam_model == MIBA_MODEL_BAL) { K[6 * c] = o[6]; K[6 * c + 1] = o[6]; K[6 * c + 4] = o[7]; K[6 * c + 5] = o[8]; }   // ox, oy are not the solver's
   }
   if (!X) return MIBA_OK;
+  if (snap >= 0) {
+    const double* pts = h->snap_X[snap];
+    const int32_t* po = h->plan_ref().pt_orig.data() + h->pt_base;
+    plan_parallel_for((int64_t)h->n_pt, [&](int64_t a, int64_t b) {
+      for (int64_t q = a; q < b; ++q) {
+        const size_t o = (size_t)po[q];
+        X[3 * o] = pts[3 * q]; X[3 * o + 1] = pts[3 * q + 1]; X[3 * o + 2] = pts[3 * q + 2];
+      }
+    });
+    return MIBA_OK;
+  }
   const size_t n_act = h->plan_ref().pt_orig.size();
   // pinned staging buffer, kept: per-iteration state pulls (update_state_every_iteration) copy at full PCIe rate
   const size_t need = 3 * (n_act ? n_act : 1);
@@ -2354,8 +2451,11 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
   if (multi_rank(h) && h->cfg.world_size > 1 && !h->grp) {
     // one process per rank: every rank contributes its own points to a zero-filled buffer; sum = gather
     // (the ranks of a single-process group write their own points straight into the caller's array instead)
-    double* d_all = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_all, 3 * (n_act ? n_act : 1) * sizeof(double)));
+    if (!h->d_gather) {
+      const int rca = dev_alloc(h, &h->d_gather, 3 * (n_act ? n_act : 1));   // kept until the problem is replaced
+      if (rca) return rca;
+    }
+    double* d_all = h->d_gather;
     hipError_t e = hipMemsetAsync(d_all, 0, 3 * n_act * sizeof(double), h->st);
     if (e == hipSuccess && h->n_pt)
       e = hipMemcpyAsync(d_all + 3 * (size_t)h->pt_base, h->d_X, 3 * (size_t)h->n_pt * sizeof(double), hipMemcpyDeviceToDevice, h->st);
@@ -2363,7 +2463,6 @@ int miba_get_state(miba_handle h, double* R, double* T, double* K, double* X) {
     if (e == hipSuccess) rcg = allreduce(h, d_all, 3 * n_act, ncclSum);
     if (e == hipSuccess && rcg == MIBA_OK) e = hipMemcpyAsync(pts, d_all, 3 * n_act * sizeof(double), hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
-    (void)hipFree(d_all);
     if (rcg != MIBA_OK) return rcg;
     if (e != hipSuccess) return fail(h, MIBA_ERR_HIP, "point download failed: %s", hipGetErrorString(e));
     const int32_t* po = h->plan_ref().pt_orig.data();
@@ -2676,12 +2775,87 @@ int miba_time_matvec(miba_handle h, const double* probe, int32_t reps, double* a
   return MIBA_OK;
 }
 
+// Iteration callbacks beside the solver (options.async_callbacks): one worker thread per solve runs the caller's callback for
+// iteration k while the solver works on iteration k + 1.  Before the call it waits for the snapshot of iteration k on every rank of
+// the handle and points miba_get_state at it.  One job at a time: the solver submits iteration k after the callback of k - 1
+// has returned, and takes that callback's verdict then (a stop therefore takes effect one iteration late).
+struct CallbackWorker {
+  miba_handle h;
+  miba_iteration_callback cb;
+  void* user;
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  bool has_job = false, busy = false, quit = false;
+  miba_iteration job{};
+  int verdict = MIBA_SOLVER_CONTINUE;
+  CallbackWorker(miba_handle h_, miba_iteration_callback cb_, void* user_) : h(h_), cb(cb_), user(user_), th([this] { run(); }) {}
+  ~CallbackWorker() {
+    { std::lock_guard<std::mutex> l(m); quit = true; }
+    cv.notify_all();
+    th.join();
+  }
+  void run() {
+    for (;;) {
+      miba_iteration it;
+      {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return quit || has_job; });
+        if (!has_job) return;
+        it = job;
+        has_job = false;
+      }
+      std::vector<miba_handle> ranks;
+      if (h->grp) ranks = h->grp->sub; else ranks.push_back(h);
+      bool ok = true;
+      for (miba_handle s : ranks) {
+        // the rank's solver thread publishes the snapshot of iteration k at the top of its loop
+        while (s->snap_seq.load(std::memory_order_acquire) < it.iteration) {
+          { std::lock_guard<std::mutex> l(m); if (quit) { ok = false; break; } }
+          if (h->grp && h->grp->abort.load(std::memory_order_acquire)) { ok = false; break; }
+          sched_yield();
+        }
+        if (!ok) break;
+        const int b = s->snap_buf_of[it.iteration & 1];
+        (void)hipSetDevice(s->device);
+        if (b < 0 || hipEventSynchronize(s->ev_snap[b]) != hipSuccess) { ok = false; break; }
+        s->snap_read = b;
+      }
+      int r = MIBA_SOLVER_ABORT;
+      if (ok) r = cb(&it, user);
+      for (miba_handle s : ranks) s->snap_read = -1;
+      {
+        std::lock_guard<std::mutex> l(m);
+        verdict = r;
+        busy = false;
+      }
+      cv.notify_all();
+    }
+  }
+  // waits for the callback in flight (if any) and returns its verdict
+  int wait() {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return !busy && !has_job; });
+    const int r = verdict;
+    verdict = MIBA_SOLVER_CONTINUE;
+    return r;
+  }
+  void submit(const miba_iteration& it) {
+    { std::lock_guard<std::mutex> l(m); job = it; has_job = true; busy = true; }
+    cv.notify_all();
+  }
+};
+
 int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback cb, void* user, miba_summary* summary) {
   if (h && h->owned) {
     // every rank runs the same LM loop on its own thread; the callback belongs to rank 0 (the caller's thread), which
     // hands its verdict to the others once per iteration (group_exchange_stop)
     std::vector<miba_summary> sm(h->owned->n);
-    return group_run(h, [&](miba_handle s, int r) { return miba_solve(s, opt, r ? nullptr : cb, r ? nullptr : user, r ? &sm[r] : summary); });
+    h->owned->async_cb.store(cb && opt && opt->async_callbacks ? 1 : 0);
+    for (miba_handle s : h->owned->sub) { s->snap_seq.store(-1); s->snap_last = -1; s->snap_buf_of[0] = s->snap_buf_of[1] = -1; }
+    const int rcg = group_run(h, [&](miba_handle s, int r) { return miba_solve(s, opt, r ? nullptr : cb, r ? nullptr : user, r ? &sm[r] : summary); });
+    h->owned->async_cb.store(0);
+    return rcg;
   }
   if (!h || !h->has_problem || !opt) return fail(h, MIBA_ERR_INVALID, "bad argument / no problem");
   HIPCHK(h, hipSetDevice(h->device));
@@ -2741,6 +2915,12 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
   it.cumulative_time_in_seconds = it.iteration_time_in_seconds;
   bool schur_ready = true;   // schur_init done for (current J, current radius)
   bool user_stop = false;
+  // callbacks beside the solver: this rank runs the worker (it has the callback), every rank of the handle takes snapshots
+  const bool async_cb = cb && o.async_callbacks;
+  const bool snap_on = async_cb || (h->grp && h->grp->async_cb.load());
+  if (!h->grp) { h->snap_seq.store(-1); h->snap_last = -1; h->snap_buf_of[0] = h->snap_buf_of[1] = -1; }
+  std::unique_ptr<CallbackWorker> worker;
+  if (async_cb) worker.reset(new CallbackWorker(h, cb, user));
 
   for (;;) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue
@@ -2753,9 +2933,17 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
     // verdicts that depend on the caller or on a clock (callback result, time limit): in a single-process group they are
     // rank 0's, handed to the other ranks here, so that every rank leaves the loop in the same iteration
     int stop = 0;
+    if (snap_on) {
+      rc = snapshot_enqueue(h, it.iteration, it.iteration == 0 || it.step_is_successful);
+      if (rc) return rc;
+    }
     if (cb) {
       const double tc = now_s();
-      const int r = cb(&it, user);
+      int r;
+      if (async_cb) {
+        r = worker->wait();   // the callback of the iteration before (if it is still running, the solver waits here)
+        if (r == MIBA_SOLVER_CONTINUE) worker->submit(it);
+      } else r = cb(&it, user);
       t_callbacks += now_s() - tc;
       if (r == MIBA_SOLVER_ABORT) stop = 1;
       else if (r == MIBA_SOLVER_TERMINATE_SUCCESSFULLY) stop = 2;
@@ -2799,6 +2987,7 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
     // The candidate cost is evaluated before the model cost change has been looked at (the step is almost always
     // valid): its partial sum sits next to those of the back-substitution, so one all-reduce of four scalars and one
     // host read serve both.
+    if (snap_on && (rc = snapshot_guard(h))) return rc;
     rc = backsub_and_candidate(h, false);
     if (rc) return rc;
     t_linear += now_s() - tl;
@@ -2883,6 +3072,15 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
     }
     it.iteration_time_in_seconds = now_s() - t_it;
     it.cumulative_time_in_seconds = now_s() - t_start - t_callbacks;
+  }
+  if (worker) {
+    // the last callback submitted: its verdict can only turn the termination into the caller's
+    const double tc = now_s();
+    const int r = worker->wait();
+    t_callbacks += now_s() - tc;
+    if (!user_stop && r == MIBA_SOLVER_ABORT) { S.termination_type = MIBA_USER_FAILURE; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_ABORT."); }
+    else if (!user_stop && r == MIBA_SOLVER_TERMINATE_SUCCESSFULLY) { S.termination_type = MIBA_USER_SUCCESS; snprintf(S.message, sizeof(S.message), "User callback returned SOLVER_TERMINATE_SUCCESSFULLY."); }
+    worker.reset();
   }
   rc = sync_stream(h);
   if (rc) return rc;

@@ -233,6 +233,14 @@ void BundleAdjustment::solve() {
     o.min_linear_solver_iterations = options.min_linear_solver_iterations;
     o.max_num_consecutive_invalid_steps = options.max_num_consecutive_invalid_steps;
     o.update_state_every_iteration = options.update_state_every_iteration ? 1 : 0;
+    // update_state_every_iteration + callbacks (src/BundleAdjustment.cpp:104-105) off the solver's critical path: the library
+    // copies the state of every iteration into pinned snapshots on a second stream and runs the trampoline below on a worker
+    // thread, from the snapshot, while the device works on the next iteration (BA_ASYNC_CALLBACKS=0: on this thread, between
+    // iterations, as ceres::Solve does).  The arrays R, T, intrinsics, X are only touched by that worker during solve().
+    {
+        const char *ac = getenv("BA_ASYNC_CALLBACKS");
+        o.async_callbacks = (ac && ac[0] == '0') ? 0 : 1;
+    }
     o.minimizer_progress_to_stdout = options.minimizer_progress_to_stdout ? 1 : 0;
     o.initial_trust_region_radius = options.initial_trust_region_radius;
     o.max_trust_region_radius = options.max_trust_region_radius;

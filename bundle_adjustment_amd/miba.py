@@ -64,7 +64,7 @@ class Options(C.Structure):
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
                 ("parameter_tolerance", C.c_double), ("eta", C.c_double), ("eta_exact", C.c_double),
                 ("max_solver_time_in_seconds", C.c_double),
-                ("loss_type", C.c_int32), ("reserved", C.c_int32), ("loss_scale", C.c_double)]
+                ("loss_type", C.c_int32), ("async_callbacks", C.c_int32), ("loss_scale", C.c_double)]
 
 
 class Iteration(C.Structure):

@@ -141,7 +141,12 @@ typedef struct {
    * the reference passes nullptr (src/BundleAdjustment.cpp:69) = MIBA_LOSS_NONE, the default.  HUBER / CAUCHY are
    * ceres::HuberLoss(loss_scale) / ceres::CauchyLoss(loss_scale); every linear solver type and preconditioner. */
   int32_t loss_type;
-  int32_t reserved;
+  int32_t async_callbacks;                  /* 0 (default): the iteration callback runs on the calling thread between iterations, as
+                                               ceres::IterationCallback does.  1: it runs on a worker thread of the solve while the solver
+                                               works on the next iteration; after every iteration that changed the state the cameras and
+                                               points are copied on a second stream into one of two pinned buffers, and miba_get_state
+                                               called from inside the callback reads that snapshot (with one process per GPU: this rank's
+                                               points only).  A stop verdict takes effect one iteration late. */
   double loss_scale;                        /* the 'a' of HuberLoss / CauchyLoss, in residual units (pixels) */
 } miba_options;
 
