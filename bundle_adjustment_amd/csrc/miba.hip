@@ -183,6 +183,7 @@ struct miba_handle_s {
   int32_t* d_tail_rec = nullptr;                  // [tail_n_vw][kTailRec] camera ranges of the tail's waves
   long long* d_tail_dbg = nullptr;                // MIBA_TAIL_DEBUG=1: phase time stamps of the tail's workgroups
   unsigned* d_bar = nullptr;                      // barrier counter of pcg_tail
+  unsigned long long* d_clk = nullptr;            // [4] clock stamps of one workgroup of the last product launch (measurement)
   int cam_model = 0;                              // MIBA_MODEL_*: camera model of the problem (miba_problem.camera_model)
   std::vector<double> principal;                  // model 1: (ox, oy) per camera that the uploaded observations carry
   Loss loss = {kLossNone, 1.0};                   // robust loss of the current solve (options.loss_type / loss_scale)
@@ -629,7 +630,7 @@ void mf_matvec_tiles(miba_handle h, const double* x, Ctl* ctl, int pcg_iter, boo
   else if (h->k3_cm)
     hipLaunchKernelGGL(k_mf_matvec_cm, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant,
                        h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec, x,
-                       h->d_slab9, ctl, CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64});
+                       h->d_slab9, ctl, CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64, h->d_clk});
   else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
 #undef MIBA_MATVEC_ARGS
 }
@@ -2204,6 +2205,8 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   ALLOC(h->d_sum, S_COUNT); ALLOC(h->d_max, S_COUNT);
   ALLOC(h->d_ctl, 2);
   ALLOC(h->d_bar, kBarWords);
+  ALLOC(h->d_clk, 4);
+  HIPCHK(h, hipMemset(h->d_clk, 0, 4 * sizeof(unsigned long long)));
   h->d_tail_dbg = nullptr;
   if (getenv("MIBA_TAIL_DEBUG")) { ALLOC(h->d_tail_dbg, 8 * (size_t)h->tail_nb); HIPCHK(h, hipMemset(h->d_tail_dbg, 0, 64 * (size_t)h->tail_nb)); }
   UP(h->d_tiles, tiles.data(), nt);
@@ -3114,6 +3117,13 @@ int miba_get_kernel_times(miba_handle h, miba_kernel_times* out) {
   out->n_tiles = h->n_tiles;
   out->n_cam = h->n_cam;
   out->product_layout = h->k3_cm;
+  out->product_clock_mhz = 0.0;
+  if (h->has_problem && h->d_clk) {
+    // shader cycles / 10 ns ticks between the start and the end of one workgroup of the last product launch that did work
+    unsigned long long c[4] = {0, 0, 0, 0};
+    if (hipMemcpy(c, h->d_clk, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess && c[3] > c[1] && c[2] > c[0])
+      out->product_clock_mhz = 100.0 * (double)(c[2] - c[0]) / (double)(c[3] - c[1]);
+  }
   return MIBA_OK;
 }
 

@@ -31,7 +31,14 @@ struct PeerSignals {            // one per rank, in that rank's fine-grained dev
   uint32_t blocks_pushed;
   uint32_t timeout;             // a bounded spin ran out
   uint32_t pad[13];
+  // exchange inside the PCG tail kernel (pcg_tail<MODE, 2>, miba_pcg.hpp): xready[j] = epoch: rank j's share of q of that
+  // exchange has arrived in this rank's exchange buffer (written by rank j); xarrive: workgroups of the own tail kernel that
+  // have finished pushing (only grows)
+  uint32_t xready[kMaxRanks];
+  uint32_t xarrive;
+  uint32_t pad2[23];
 };
+static_assert(sizeof(PeerSignals) == 256, "signal block layout");
 
 struct PeerArgs {
   double* stage[kMaxRanks];     // [in kPeerChunk | out kPeerChunk] of every rank

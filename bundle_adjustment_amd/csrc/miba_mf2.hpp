@@ -34,6 +34,8 @@ struct CmArgs {
   const uint8_t* slot;   // [sub-tile][256] LDS slot of the sub-tile's k-th point
   const int4* cam64;   // [tile][64] per camera slot: {camera, slab row, first accumulator row | rows << 8, 0}: addressed by the
                        // block index alone, so that a workgroup's first loads already fetch them
+  unsigned long long* clk;   // [4] measurement: shader-clock and 100 MHz counter at the start and the end of ONE workgroup (the
+                             // middle one of the grid), from which the host derives the clock the kernel ran at; may be null
 };
 
 // MIBA_CM_STAMPS (debug builds): cycles per phase, summed over the waves, in a device array that miba_time_matvec prints
@@ -233,6 +235,10 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
   for (int m = 0; m < 3; ++m) f64[m] = A.cam64[(size_t)ti * kMaxCamSlots + min((tid + m * kChunk) / 9, kMaxCamSlots - 1)];
   if (done) return;
   CM_T(k0);
+  // in-kernel clock (MI355X_MICROARCH.md: s_memtime ticks are shader cycles, s_memrealtime ticks are 10 ns): one workgroup stamps
+  const bool clk_on = A.clk != nullptr && blockIdx.x == (gridDim.x >> 1);
+  unsigned long long clk_c0 = 0, clk_r0 = 0;
+  if (clk_on) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   if ((int)blockIdx.x < n_giant) {
     mf_matvec_block<true, false>(tile_list[blockIdx.x], s_cam, s_acc, s4, tiles, grps, idx, ocam, wl, tile_cams, slab_row, ct, cm, sc, X, ptrec,
                                  nullptr, x, slab);
@@ -278,6 +284,10 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
   }
   CM_T(k3);
   CM_ADD(7, k2, k3); CM_ADD(8, k0, k3); CM_ADD(9, 0, 1);
+  if (clk_on) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) { A.clk[0] = clk_c0; A.clk[1] = clk_r0; A.clk[2] = c1; A.clk[3] = r1; }
+  }
 }
 
 }  // namespace miba

@@ -17,10 +17,15 @@
 // ORDER: the partial-sum store and the arrival atomic go to different L2 channels and may complete out of order, so the
 // arriving thread waits for its stores to be acknowledged (s_waitcnt vmcnt(0)) before it arrives.
 // A barrier that is not reached within two seconds (the grid was not resident after all) ends the solve with a failure status
-// instead of hanging.  With several ranks the camera-side sum stays a kernel of its own (the all-reduce sits behind it) and
-// the tail starts at B.
+// instead of hanging.  With several ranks under RCCL or the host transport the camera-side sum stays a kernel of its own (the
+// all-reduce sits behind it) and the tail starts at B.  With several ranks of ONE process under the peer transport the exchange is
+// part of this kernel (REDUCE == 2): phase A pushes this rank's share of q straight into every rank's
+// fine-grained exchange buffer, the last workgroup to finish raises the rank's flag at every peer, everybody waits for all
+// flags and sums the N shares of its cameras in rank order (the same bits on every rank); B and C follow as with one rank:
+// one launch per PCG iteration after the tiles, no collective call, one cross-device wait.
 #pragma once
 
+#include "miba_comm.hpp"
 #include "miba_mf.hpp"
 
 namespace miba {
@@ -147,6 +152,14 @@ struct TailArgs {
   int a_on_x;          // MODE 3: the product's input is x (residual refresh), not p
   unsigned* bar;       // barrier counters
   long long bar_timeout;   // ticks of the 100 MHz counter a barrier waits before it gives up (2 s; tests shorten it)
+  // several ranks: phases B and C take cameras 7 vw .. 7 vw + 6 per wave (the same on every rank, so that the partial sums the
+  // ranks form are the same numbers in the same order) instead of the wave records, whose cuts follow the rank's own slab rows
+  int uniform;
+  // REDUCE == 2: the exchange of q between the ranks of one process (peer transport)
+  double* xstage[kMaxRanks];      // rank j's exchange buffer [2 (parity of epoch)][n_ranks][9 n_cam], fine-grained, peer-mapped
+  PeerSignals* xsig[kMaxRanks];   // rank j's signal block
+  int n_ranks, rank;
+  uint32_t epoch;                 // exchanges so far on this handle (the same on every rank)
   int split;           // 0: one launch.  The form WITHOUT grid barriers (a device shared with other work, where the grid may not be
                        // resident as a whole): phase A as pcg_tail<3>, then 1: this launch ends after phase B, 2: this launch is
                        // phase C (scalars recomputed from the partial sums, vectors from memory)
@@ -174,7 +187,8 @@ __device__ __forceinline__ void tail_sum_partials2(const double* pa, int na, con
 // MODE 2: second half: A on q = S x (no p.q), r = b - q, Q, z, r.z, then C.
 // MODE 3: phase A alone (several ranks: the all-reduce of q and of the p.q partials behind it follows, then the tail without
 //         REDUCE): q = S v of this rank's slab rows, v = x when a_on_x is set (no partials then), else p.
-// REDUCE: phase A is part of this launch (one rank); otherwise q and the p.q partials are there already.
+// REDUCE 1: phase A is part of this launch (one rank); 0: q and the p.q partials are there already (several ranks, the all-reduce
+// has run); 2: phase A and the exchange with the other ranks of the process are part of this launch.
 //
 // Lane (sub, k) of a wave owns entry k of camera cam0 + sub (cpw cameras per wave, nine lanes each).  When one round covers all
 // cameras (single: up to 7 x kTailWaves x 256 = 14,336 of them) the entries of x, p, r, b and the row of M^-1 are loaded before the first
@@ -184,7 +198,7 @@ __device__ __forceinline__ void tail_sum_partials2(const double* pa, int na, con
 // lane (g, k) takes rows g, g + 7, g + 14, ... so that a load instruction covers 504 contiguous bytes whatever the row counts
 // of the cameras are; a lane's rows run through the cameras in order, and it hands its sum to LDS each time it crosses into
 // the next camera; the camera's lanes then add the seven partial sums in a fixed order.
-template <int MODE, bool REDUCE>
+template <int MODE, int REDUCE>
 __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   __shared__ double s32[2 * kTailWaves];
   __shared__ int s_ok;
@@ -197,7 +211,9 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   // wave records vw0, vw0 + n_waves, ...: consecutive records go to different workgroups, so that every workgroup has work
   // when there are fewer records than waves
   const int vw0 = wv * nb + blockIdx.x, n_waves = nb * kTailWaves;
-  const bool single = a.n_vw <= n_waves && a.split == 0;   // one round: values are carried in registers
+  const int n_vw_bc = a.uniform ? (a.n_cam + 6) / 7 : a.n_vw;   // records of phases B and C
+  // one round: values are carried in registers
+  const bool single = (REDUCE == 1 ? a.n_vw : n_vw_bc) <= n_waves && a.split == 0;
   // the first record is fetched together with the control block (one trip to memory instead of two)
   const int rec_first = (vw0 < a.n_vw) ? a.wave_rec[(size_t)kTailRec * vw0 + min(lane, kTailRec - 1)] : 0;
   Ctl c = a.ctl[(j - 1) & 1];   // C_{j-1}
@@ -275,9 +291,52 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
         double rr = cf[0] * v0 + cf[1] * v1 + cf[2] * v2 + cf[3] * v3 + cf[4] * v4 + cf[5] * v5 + cf[6] * tot;
         rr *= scv;
         rr += a.diag_w * d2v * xv;
-        if (single && MODE != 3) { c_q = rr; if (MODE != 2) c_p = xv; else c_x = xv; }
-        else a.q[i] = rr;
-        xy += xv * rr;
+        if (REDUCE == 2) {
+          // this rank's share of q[i] into every rank's exchange buffer (write-through, system scope)
+          const size_t at = ((size_t)(a.epoch & 1u) * a.n_ranks + a.rank) * 9 * (size_t)a.n_cam + i;
+          for (int jr = 0; jr < a.n_ranks; ++jr) peer_std(a.xstage[jr] + at, rr);
+        } else {
+          if (single && MODE != 3) { c_q = rr; if (MODE != 2) c_p = xv; else c_x = xv; }
+          else a.q[i] = rr;
+          xy += xv * rr;
+        }
+      }
+    }
+    if (REDUCE == 2) {
+      // every push of this workgroup acknowledged, then the workgroup arrives; the last one to arrive raises this rank's flag at
+      // every peer; then everybody waits for the flags of all ranks (in the own signal block)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      PeerSignals* me = a.xsig[a.rank];
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&me->xarrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old % (unsigned)nb == (unsigned)nb - 1u) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          for (int jr = 0; jr < a.n_ranks; ++jr) peer_st(&a.xsig[jr]->xready[a.rank], a.epoch);
+        }
+        s_ok = 1;
+      }
+      __syncthreads();
+      if (tid < a.n_ranks && !peer_wait(&me->xready[tid], a.epoch, &me->timeout)) s_ok = 0;
+      __syncthreads();
+      if (!s_ok) {
+        if (writer) tail_timed_out(a.ctl);
+        return;
+      }
+      // q = the shares summed in rank order, for the cameras phases B and C give this lane
+      const double* mine = a.xstage[a.rank] + (size_t)(a.epoch & 1u) * a.n_ranks * 9 * (size_t)a.n_cam;
+      xy = 0.0;
+      for (int vw = vw0; vw < n_vw_bc; vw += n_waves) {
+        const int cam0 = 7 * vw, ncw = min(7, a.n_cam - cam0);
+        if (sub < ncw) {
+          const size_t i = 9 * (size_t)(cam0 + sub) + k;
+          double v = peer_ldd(mine + i);
+          for (int jr = 1; jr < a.n_ranks; ++jr) v += peer_ldd(mine + (size_t)jr * 9 * (size_t)a.n_cam + i);
+          const double xv = v_in[i];
+          if (single) { c_q = v; if (MODE != 2) c_p = xv; else c_x = xv; }
+          else a.q[i] = v;
+          xy += xv * v;
+        }
       }
     }
     if (MODE == 3) {
@@ -302,8 +361,9 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   // ---- B: alpha and the vector updates ----
   // single: the lane's entries of the vectors and its row of M^-1 are requested BEFORE the partial sums, so that they arrive
   // with them (loads return in order): nothing is waited for twice
-  const int cam0_1 = __shfl(rec_first, 0, 64), ncw_1 = __shfl(rec_first, 1, 64);
-  if (single && sub < ncw_1 && vw0 < a.n_vw) {
+  const int cam0_1 = a.uniform ? 7 * vw0 : __shfl(rec_first, 0, 64);
+  const int ncw_1 = a.uniform ? min(7, a.n_cam - 7 * vw0) : __shfl(rec_first, 1, 64);
+  if (single && sub < ncw_1 && vw0 < n_vw_bc) {
     const size_t i = 9 * (size_t)(cam0_1 + sub) + k;
     if (!REDUCE) { c_q = a.q[i]; c_p = a.p[i]; c_x = a.x[i]; }
     else if (MODE != 2) c_x = a.x[i];
@@ -323,11 +383,14 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   TAIL_STAMP(3);
   if (!pq_bad && !alpha_bad && a.split != 2) {
     double a_q = 0.0, a_rho = 0.0;
-    for (int vw = vw0; vw < a.n_vw; vw += n_waves) {
+    for (int vw = vw0; vw < n_vw_bc; vw += n_waves) {
       int cam0 = cam0_1, ncw = ncw_1;
       if (vw != vw0) {
-        const int rec = a.wave_rec[(size_t)kTailRec * vw + (lane & 1)];
-        cam0 = __shfl(rec, 0, 64); ncw = __shfl(rec, 1, 64);
+        if (a.uniform) { cam0 = 7 * vw; ncw = min(7, a.n_cam - cam0); }
+        else {
+          const int rec = a.wave_rec[(size_t)kTailRec * vw + (lane & 1)];
+          cam0 = __shfl(rec, 0, 64); ncw = __shfl(rec, 1, 64);
+        }
       }
       const bool on = sub < ncw;
       const int cam = on ? cam0 + sub : cam0;
@@ -383,7 +446,7 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
 
   // ---- C: end of iteration j, direction of iteration j + 1 (pcg_chkdir(j + 1)) ----
   // (a single-round MODE 2 has not had p in its registers: requested before the partial sums, like the vectors of phase B)
-  if (single && MODE == 2 && REDUCE && sub < ncw_1 && vw0 < a.n_vw) c_p = a.p[9 * (size_t)(cam0_1 + sub) + k];
+  if (single && MODE == 2 && REDUCE && sub < ncw_1 && vw0 < n_vw_bc) c_p = a.p[9 * (size_t)(cam0_1 + sub) + k];
   double qs = 0.0, rho_n = 0.0;
   if (!pq_bad && !alpha_bad) tail_sum_partials2(a.part_q, nb, part_rho_next, nb, s32, qs, rho_n);
   c.n_it = j;
@@ -420,11 +483,14 @@ __global__ __launch_bounds__(kTailThreads) void pcg_tail(const TailArgs a) {
   if (bad) { c.done = 1; c.status = 2; c.n_it = j + 1; }
   if (writer) a.ctl[j & 1] = c;
   if (bad) return;
-  for (int vw = vw0; vw < a.n_vw; vw += n_waves) {
+  for (int vw = vw0; vw < n_vw_bc; vw += n_waves) {
     int cam0 = cam0_1, ncw = ncw_1;
     if (vw != vw0) {
-      const int rec = a.wave_rec[(size_t)kTailRec * vw + (lane & 1)];
-      cam0 = __shfl(rec, 0, 64); ncw = __shfl(rec, 1, 64);
+      if (a.uniform) { cam0 = 7 * vw; ncw = min(7, a.n_cam - cam0); }
+      else {
+        const int rec = a.wave_rec[(size_t)kTailRec * vw + (lane & 1)];
+        cam0 = __shfl(rec, 0, 64); ncw = __shfl(rec, 1, 64);
+      }
     }
     if (sub < ncw) {
       const size_t i = 9 * (size_t)(cam0 + sub) + k;

@@ -218,6 +218,8 @@ typedef struct {
   int64_t n_tiles;
   int32_t n_cam;
   int32_t product_layout;  /* 1: the implicit-Schur product walks camera-major sub-tiles (csrc/miba_mf2.hpp), 0: point-major wavelets */
+  double product_clock_mhz; /* shader clock the last product launch ran at: (s_memtime ticks) / (s_memrealtime ticks) x 100 MHz over the
+                               lifetime of one workgroup in the middle of its grid; 0 when not measured (point-major product) */
 } miba_kernel_times;
 
 void miba_default_options(miba_options* o);
