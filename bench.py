@@ -277,7 +277,8 @@ def main():
     # per-PCG-iteration cost: everything between two products (camera reduction, vector kernels, launch gaps, polls)
     t_lin = sum(r["iteration_time_in_seconds"] for r in timed)
     pcg = {"pcg_iterations": n_cg, "ms_per_pcg_iteration_all_in": 1e3 * dt / max(1, n_cg),
-           "product_ms": k3_ms, "tail_ms": red_ms, "launches_per_iteration": 2 if args.gpus == 1 else 4,
+           "product_ms": k3_ms, "tail_ms": red_ms, "launches_per_iteration": kt.get("pcg_launches"),
+           "exchange": {0: "none (one rank)", 1: "all-reduce call between phase A and the rest of the tail", 2: "inside the tail kernel (peer transport)"}.get(kt.get("pcg_exchange")),
            "note": "all_in = timed wall time / PCG iterations (K2, K4, K1' and host reads included); product = k_mf_matvec over "
                    "the tiles, tail = pcg_tail (camera-side sum, vector updates, scalars, next direction in one launch; with "
                    "several ranks only the camera-side sum is timed here), both from HIP events on sampled iterations"}

@@ -76,6 +76,8 @@ struct RankGroup {
   // kCommPeer: per rank, fine-grained device memory: [in | out] staging halves and the signal block
   std::vector<double*> pstage;
   std::vector<PeerSignals*> psig;
+  // kCommPeer: per rank, the exchange buffer of the PCG tail kernel [2][n ranks][9 n_cam] (fine-grained; allocated with the problem)
+  std::vector<double*> xstage;
   // decisions of rank 0 handed to the other ranks once per LM iteration (callback result, time limit)
   std::atomic<int> ctl_stop[2];
   // the solve in progress runs its iteration callback on a worker thread, from state snapshots (options.async_callbacks)
@@ -142,6 +144,8 @@ struct miba_handle_s {
   RankGroup* grp = nullptr;  // rank handle of a single-process multi-device group: the group it belongs to
   RankGroup* owned = nullptr;  // group handle (what miba_create_multi returns): the group it owns; it has no device state
   uint32_t peer_epoch = 0;   // kCommPeer: all-reduces issued so far (identical on every rank)
+  int pcg_launches = 0, pcg_exchange = 0;   // shape of the last PCG solve's iteration (miba_kernel_times)
+  uint32_t x_epoch = 0;      // kCommPeer: exchanges inside the PCG tail kernel issued so far (identical on every rank)
   double* static_scratch = nullptr;   // this device's copy of the file-scope scratch array (miba_dense_spd_solve_static)
   std::string err;
   bool has_problem = false;
@@ -291,6 +295,7 @@ int upload(miba_handle h, T* dst, const T* src, size_t count) {
 void free_problem(miba_handle h) {
   for (void* p : h->allocs) (void)hipFree(p);
   h->allocs.clear();
+  if (h->grp && (size_t)h->cfg.rank < h->grp->xstage.size()) h->grp->xstage[h->cfg.rank] = nullptr;   // (was one of the allocations)
   h->has_problem = false;
   h->jac_valid = false;
   h->scale_valid = false;
@@ -695,10 +700,12 @@ int unit_scale_masked(miba_handle h) {
 // Per iteration two launches: the tiles' side of the product (k_mf_matvec) and pcg_tail (miba_pcg.hpp: camera-side sum, vector
 // updates, scalars, next direction); with several ranks the camera-side sum and its all-reduce stand between them.  The control
 // block is device-resident and double-buffered (see miba_kernels.hpp).
+// reduce: 0 = q is there already, 1 = phase A in the launch, 2 = phase A and the exchange between the ranks in the launch
 template <int MODE>
-void launch_tail(miba_handle h, const TailArgs& A, bool reduce) {
-  if (reduce) hipLaunchKernelGGL((pcg_tail<MODE, true>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
-  else hipLaunchKernelGGL((pcg_tail<MODE, false>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
+void launch_tail(miba_handle h, const TailArgs& A, int reduce) {
+  if (reduce == 2) hipLaunchKernelGGL((pcg_tail<MODE, 2>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
+  else if (reduce == 1) hipLaunchKernelGGL((pcg_tail<MODE, 1>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
+  else hipLaunchKernelGGL((pcg_tail<MODE, 0>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, A);
 }
 
 int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_every, int* n_it, int* status) {
@@ -716,9 +723,17 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
   A.diag_w = h->cfg.rank == 0 ? 1.0 : 0.0;
   A.p = h->d_pp; A.q = h->d_pq; A.b = h->d_rhs; A.Minv = h->d_Minv; A.x = h->d_px; A.r = h->d_pr; A.z = h->d_pz;
   A.ctl = h->d_ctl;
-  // one rank: the tail's own p.q partials; several ranks: the camera reduction's, behind q so that one all-reduce takes both
-  A.part_pq = multi ? h->d_pq + n : h->d_part_pcg + 4 * kPcgMaxBlocks;
   A.n_pq = nb;
+  // several ranks: phases B and C walk the cameras in the same order on every rank (the wave records follow the rank's own rows)
+  A.uniform = multi ? 1 : 0;
+  // ranks of one process under the peer transport: the exchange of q is part of the tail kernel (pcg_tail<MODE, 2>)
+  const bool can_fuse = multi && h->grp && h->grp->mode == kCommPeer && !h->grp->xstage.empty() && !getenv("MIBA_TAIL_NO_FUSE") &&
+                        std::all_of(h->grp->xstage.begin(), h->grp->xstage.end(), [](const double* q) { return q != nullptr; });
+  if (can_fuse) {
+    for (int q = 0; q < h->grp->n; ++q) { A.xstage[q] = h->grp->xstage[q]; A.xsig[q] = h->grp->psig[q]; }
+    A.n_ranks = h->grp->n;
+    A.rank = h->cfg.rank;
+  }
   A.part_q = part_q; A.part_rho0 = part_rho[0]; A.part_rho1 = part_rho[1];
   A.q_tol = q_tol; A.min_it = min_it; A.max_it = max_it;
   A.bar = h->d_bar;
@@ -732,7 +747,7 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
       TailArgs R = A;
       R.j = j;
       R.a_on_x = on_x ? 1 : 0;
-      hipLaunchKernelGGL((pcg_tail<3, true>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, R);
+      hipLaunchKernelGGL((pcg_tail<3, 1>), dim3(h->tail_nb), dim3(kTailThreads), 0, h->st, R);
     }
     HIPCHK(h, hipGetLastError());
     return allreduce(h, h->d_pq, n + (on_x ? 0 : (size_t)nb), ncclSum);
@@ -740,18 +755,26 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
   // The tail after phase A.  One launch with two grid barriers when the device is this solver's own; without barriers
   // (tail_split: MIBA_TAIL_SPLIT=1, or after a barrier of this handle has timed out once) phase B and phase C are launches of
   // their own, which any amount of foreign work on the device can delay but not deadlock.
-  auto tail_rest = [&](auto mode_tag, bool reduce) {
+  auto tail_rest = [&](auto mode_tag, int reduce) {
     constexpr int MODE = decltype(mode_tag)::value;
+    if (reduce == 2) A.epoch = ++h->x_epoch;
     if (!h->tail_split || MODE == 1) { launch_tail<MODE>(h, A, reduce); return; }
     TailArgs B = A;
     B.split = 1;
-    launch_tail<MODE>(h, B, false);
+    launch_tail<MODE>(h, B, 0);
     B.split = 2;
-    launch_tail<MODE>(h, B, false);
+    launch_tail<MODE>(h, B, 0);
   };
   for (int attempt = 0;; ++attempt) {
     const bool split = h->tail_split != 0;
-    const bool own_reduce = multi || split;   // phase A as its own launch
+    const bool fused = can_fuse && !split;
+    const bool own_reduce = (multi && !fused) || split;   // phase A as its own launch
+    const int in_tail = own_reduce ? 0 : (fused ? 2 : 1);   // what the tail launch does before phase B
+    // one rank (or the exchange inside the tail): the tail's own p.q partials; several ranks with an all-reduce: the camera
+    // reduction's, behind q so that one all-reduce takes both
+    A.part_pq = (multi && !fused) ? h->d_pq + n : h->d_part_pcg + 4 * kPcgMaxBlocks;
+    h->pcg_launches = 1 + (own_reduce ? 1 : 0) + (split ? 2 : 1);
+    h->pcg_exchange = !multi ? 0 : (fused ? 2 : 1);
     HIPCHK(h, hipMemsetAsync(h->d_bar, 0, kBarWords * sizeof(unsigned), h->st));
     hipLaunchKernelGGL(pcg_start, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_rhs, h->d_Minv, h->d_px, h->d_pr, h->d_pz, h->d_ctl,
                        part_nb, part_rho[1]);
@@ -779,13 +802,13 @@ int pcg_solve(miba_handle h, double q_tol, int min_it, int max_it, int check_eve
       if (own_reduce && (rc = reduce_step(false, j, sample))) return rc;
       if (!reset) {
         Timed t(h, own_reduce ? -1 : MIBA_K_CAM_REDUCE, j, sample && !own_reduce);
-        tail_rest(std::integral_constant<int, 0>(), !own_reduce);
+        tail_rest(std::integral_constant<int, 0>(), in_tail);
       } else {
-        tail_rest(std::integral_constant<int, 1>(), !own_reduce);
+        tail_rest(std::integral_constant<int, 1>(), in_tail);
         HIPCHK(h, hipGetLastError());
         mf_matvec_tiles(h, h->d_px, cur, j, sample);   // q = S p is dead once x is updated: reuse it for S x
         if (own_reduce && (rc = reduce_step(true, j, false))) return rc;
-        tail_rest(std::integral_constant<int, 2>(), !own_reduce);
+        tail_rest(std::integral_constant<int, 2>(), in_tail);
       }
       HIPCHK(h, hipGetLastError());
       if (poll) {
@@ -1656,7 +1679,7 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
   // the PCG tail kernel meets at grid barriers: its grid may not exceed what the device holds at once
   if (e == hipSuccess) {
     int occ = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pcg_tail<0, true>, kTailThreads, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pcg_tail<0, 1>, kTailThreads, 0);
     h->tail_occ = std::max(1, occ);
   }
   if (const char* te = getenv("MIBA_TAIL_SPLIT")) h->tail_split = te[0] == '1';
@@ -1768,9 +1791,15 @@ int miba_create_multi(const int32_t* device_ids, int32_t n_devices, int32_t log_
     rc = create_rank(dev[r], r, n_devices, log_level, &G->sub[r]);
     if (rc == MIBA_OK) {
       G->sub[r]->grp = G;
-      int share = 0;
-      for (int q = 0; q < n_devices; ++q) share += dev[q] == dev[r];
-      G->sub[r]->dev_share = share;
+      // every rank takes the share of the most crowded device: the grid of the PCG tail (and with it the order of its partial
+      // sums) must be the same on every rank
+      int max_share = 0;
+      for (int a = 0; a < n_devices; ++a) {
+        int share = 0;
+        for (int q = 0; q < n_devices; ++q) share += dev[q] == dev[a];
+        max_share = std::max(max_share, share);
+      }
+      G->sub[r]->dev_share = max_share;
     }
   }
   if (rc == MIBA_OK && n_devices > 1) {
@@ -1786,6 +1815,7 @@ int miba_create_multi(const int32_t* device_ids, int32_t n_devices, int32_t log_
     } else {
       G->pstage.assign(n_devices, nullptr);
       G->psig.assign(n_devices, nullptr);
+      G->xstage.assign(n_devices, nullptr);
       for (int r = 0; r < n_devices && rc == MIBA_OK; ++r) {
         hipError_t e = hipSetDevice(dev[r]);
         for (int q = 0; q < n_devices && e == hipSuccess; ++q)
@@ -2207,6 +2237,17 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
   ALLOC(h->d_bar, kBarWords);
   ALLOC(h->d_clk, 4);
   HIPCHK(h, hipMemset(h->d_clk, 0, 4 * sizeof(unsigned long long)));
+  if (h->grp && h->grp->n > 1 && h->grp->mode == kCommPeer && (size_t)h->cfg.rank < h->grp->xstage.size()) {
+    // exchange buffer of the PCG tail kernel (pcg_tail<MODE, 2>): the q shares of all ranks, two generations.  Fine-grained, so that
+    // the peers' system-scope stores land coherently; without it (no memory) the ranks keep the all-reduce kernel between launches.
+    void* xs = nullptr;
+    const size_t bytes = 2 * (size_t)h->grp->n * 9 * nc * sizeof(double);
+    if (hipExtMallocWithFlags(&xs, bytes ? bytes : 8, hipDeviceMallocFinegrained) == hipSuccess) {
+      h->allocs.push_back(xs);
+      HIPCHK(h, hipMemset(xs, 0, bytes));
+      h->grp->xstage[h->cfg.rank] = (double*)xs;
+    } else (void)hipGetLastError();
+  }
   h->d_tail_dbg = nullptr;
   if (getenv("MIBA_TAIL_DEBUG")) { ALLOC(h->d_tail_dbg, 8 * (size_t)h->tail_nb); HIPCHK(h, hipMemset(h->d_tail_dbg, 0, 64 * (size_t)h->tail_nb)); }
   UP(h->d_tiles, tiles.data(), nt);
@@ -3117,6 +3158,8 @@ int miba_get_kernel_times(miba_handle h, miba_kernel_times* out) {
   out->n_tiles = h->n_tiles;
   out->n_cam = h->n_cam;
   out->product_layout = h->k3_cm;
+  out->pcg_launches = h->pcg_launches;
+  out->pcg_exchange = h->pcg_exchange;
   out->product_clock_mhz = 0.0;
   if (h->has_problem && h->d_clk) {
     // shader cycles / 10 ns ticks between the start and the end of one workgroup of the last product launch that did work

@@ -92,7 +92,7 @@ class KernelTimes(C.Structure):
     _fields_ = [("launches", C.c_int64 * K_COUNT), ("total_ms", C.c_double * K_COUNT),
                 ("n_slots", C.c_int64), ("n_obs_local", C.c_int64), ("n_pt_local", C.c_int64),
                 ("n_tiles", C.c_int64), ("n_cam", C.c_int32), ("product_layout", C.c_int32),
-                ("product_clock_mhz", C.c_double)]
+                ("product_clock_mhz", C.c_double), ("pcg_launches", C.c_int32), ("pcg_exchange", C.c_int32)]
 
 
 CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(Iteration), C.c_void_p)
@@ -344,7 +344,8 @@ class Solver:
         self._chk(lib().miba_get_kernel_times(self._h, C.byref(kt)), "miba_get_kernel_times")
         return dict(launches=list(kt.launches), total_ms=list(kt.total_ms), n_slots=kt.n_slots,
                     n_obs_local=kt.n_obs_local, n_pt_local=kt.n_pt_local, n_tiles=kt.n_tiles, n_cam=kt.n_cam,
-                    product_layout=kt.product_layout, product_clock_mhz=kt.product_clock_mhz)
+                    product_layout=kt.product_layout, product_clock_mhz=kt.product_clock_mhz,
+                    pcg_launches=kt.pcg_launches, pcg_exchange=kt.pcg_exchange)
 
     def reset_kernel_times(self):
         self._chk(lib().miba_reset_kernel_times(self._h), "miba_reset_kernel_times")

@@ -220,6 +220,10 @@ typedef struct {
   int32_t product_layout;  /* 1: the implicit-Schur product walks camera-major sub-tiles (csrc/miba_mf2.hpp), 0: point-major wavelets */
   double product_clock_mhz; /* shader clock the last product launch ran at: (s_memtime ticks) / (s_memrealtime ticks) x 100 MHz over the
                                lifetime of one workgroup in the middle of its grid; 0 when not measured (point-major product) */
+  int32_t pcg_launches;     /* kernel launches per ordinary PCG iteration of the last solve (product + tail = 2; with an all-reduce between
+                               phase A and the rest of the tail 3 + the collective; without grid barriers one more) */
+  int32_t pcg_exchange;     /* how q = S p crossed the ranks in the last solve: 0 one rank, 1 an all-reduce call between launches (RCCL,
+                               the peer kernel or the host transport), 2 inside the tail kernel (peer transport, ranks of one process) */
 } miba_kernel_times;
 
 void miba_default_options(miba_options* o);

@@ -109,29 +109,46 @@ def test_group_agrees_with_single_rank_giant_points(single_giant):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_peer_allreduce_kernel(single, world):
-    """the library's own 2-hop all-reduce kernel (MIBA_ALLREDUCE=peer) under the same expectations.  The rank kernels wait
+@pytest.mark.parametrize("fuse", [True, False])
+def test_peer_allreduce_kernel(single, world, fuse):
+    """the library's own transport (MIBA_ALLREDUCE=peer) under the same expectations: the 2-hop all-reduce kernel for the
+    reductions of an LM iteration, and inside the PCG either the exchange of q as part of the tail kernel (pcg_tail<MODE, 2>: one
+    launch per iteration after the tiles, the default) or, with MIBA_TAIL_NO_FUSE=1, phase A, the all-reduce kernel and the rest
+    of the tail as three launches.  The rank kernels wait
     for each other inside the launch, so on ONE device they must be resident together: at most three ranks here (a process
     has four hardware queues, GPU_MAX_HW_QUEUES, one of them the null stream's; with four ranks two rank streams share a
     queue and the kernel's bounded spin reports MIBA_ERR_RCCL instead of hanging).  On a node every rank has its own device."""
-    check(run(world, "medium", {"MIBA_ALLREDUCE": "peer"}), single)
+    env = {"MIBA_ALLREDUCE": "peer"}
+    if not fuse:
+        env["MIBA_TAIL_NO_FUSE"] = "1"
+    check(run(world, "medium", env), single)
 
 
-def test_many_cameras_on_three_ranks():
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_many_cameras_on_three_ranks(transport):
     """6,000 cameras: with three ranks sharing the device's compute units the grid of the PCG tail no longer covers the cameras
-    in one round (85 workgroups x 8 waves x 7 cameras), so its phases loop; phase A is a launch of its own with the all-reduce
-    behind it.  Same costs and PCG iteration counts as the one-rank run, whose tail does cover them in one round."""
+    in one round (85 workgroups x 8 waves x 7 cameras), so its phases loop.  Host transport: phase A is a launch of its own with
+    the all-reduce behind it; peer transport: the exchange inside the tail kernel, its sums written to memory between the phases.
+    Same costs and PCG iteration counts as the one-rank run, whose tail does cover them in one round."""
     pr = synth.make_problem(6000, 40000, 200000, seed=600)
     cams0, pts0 = synth.perturb(pr, 0.002, 0.03, seed=601)
     opt = miba.default_options(max_num_iterations=4, linear_solver_type=miba.ITERATIVE_SCHUR, function_tolerance=0.0,
                                gradient_tolerance=0.0, parameter_tolerance=0.0)
     res = []
-    for devs in (None, [0, 0, 0]):
-        s = miba.Solver(device_id=0) if devs is None else miba.Solver(devices=devs)
-        s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
-        its, summ = s.solve(opt)
-        s.close()
-        res.append(([r["cost"] for r in its], [r["linear_solver_iterations"] for r in its]))
+    old = os.environ.get("MIBA_ALLREDUCE")
+    os.environ["MIBA_ALLREDUCE"] = transport
+    try:
+        for devs in (None, [0, 0, 0]):
+            s = miba.Solver(device_id=0) if devs is None else miba.Solver(devices=devs)
+            s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+            its, summ = s.solve(opt)
+            s.close()
+            res.append(([r["cost"] for r in its], [r["linear_solver_iterations"] for r in its]))
+    finally:
+        if old is None:
+            os.environ.pop("MIBA_ALLREDUCE", None)
+        else:
+            os.environ["MIBA_ALLREDUCE"] = old
     assert res[0][1] == res[1][1]
     assert np.abs(np.array(res[0][0]) - np.array(res[1][0])).max() <= 1e-9 * res[0][0][0]
     assert res[0][0][-1] < res[0][0][0]
