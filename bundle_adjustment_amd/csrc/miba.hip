@@ -214,6 +214,18 @@ struct miba_handle_s {
   int32_t *d_sp_col_rows = nullptr, *d_sp_col_slots = nullptr, *d_sp_row_cols = nullptr, *d_sp_row_slots = nullptr;
   std::vector<int64_t> sp_col_ptr, sp_row_ptr;
   std::vector<int32_t> sp_row_last;   // column of the last tile of every tile row (-1: none)
+  // dissection of the tile graph (sparse_symbolic): the columns [sp_arc[a], sp_arc[a + 1]) of arc a touch no column of another arc, so
+  // the arcs are factored side by side on sp_st[]; the separator columns [sp_arc[n_arcs], nT) follow on the main stream.  Updates of an
+  // arc that land in separator x separator tiles (or the right-hand side of a separator column) go to private tiles of the arc
+  // (d_sp_smap: [arc][(nS + 1) x nS] slots) and are added to the matrix in a fixed order once all arcs are done (k_tchol_merge).
+  int sp_n_arcs = 1;
+  std::vector<int32_t> sp_arc;
+  int32_t *d_sp_smap = nullptr, *d_sp_merge_ptr = nullptr, *d_sp_merge_src = nullptr, *d_sp_merge_dst = nullptr;
+  int64_t sp_n_priv = 0;           // private tiles (behind the right-hand-side tiles)
+  int32_t sp_n_merge = 0;          // destination tiles with private contributions
+  int64_t sp_fill_tiles = 0;       // tiles below the diagonal after fill (reported)
+  hipStream_t sp_st[3] = {nullptr, nullptr, nullptr};   // the extra streams of the arcs
+  hipEvent_t sp_ev_fork = nullptr, sp_ev_join[3] = {nullptr, nullptr, nullptr};
   double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
   double *d_sum = nullptr, *d_max = nullptr;   // [S_COUNT] each
   Ctl* d_ctl = nullptr;
@@ -1299,7 +1311,47 @@ int sparse_symbolic(miba_handle h) {
 
   const int64_t max_tiles = (int64_t)(free_all / 2 / (4096 * sizeof(double)));
 
-  // minimum degree on the tile graph (ties: the lowest tile row, which keeps a banded problem banded)
+  // Dissection of the tile graph into arcs that can be factored side by side (the elimination order of a band is a chain: at
+  // Final-13682 1,955 tile columns of 29 us each).  The tile rows are cut by index into n_arcs equal ranges; an edge between two
+  // ranges puts its higher end into the separator (rows ascending: a valid cover of the crossing edges; on a band these are the
+  // first rows behind every cut, on a ring also the last rows, which close it).  Interiors of different arcs then share no edge, and
+  // eliminating an interior row creates fill only inside its arc and towards the separator: the arcs' columns are independent of
+  // each other, the separator rows come last.  Only camera numberings with locality (what BAL files and the stand-in have) dissect
+  // this way; if the separator takes more than a third of the rows the order stays plain minimum degree on one stream.
+  // MIBA_SPARSE_ARCS=1..4 overrides the number of arcs (tests, measurements).  Default three from 256 tile rows up: a process has four
+  // hardware queues, and with four arcs (main stream + three) two of the streams end up sharing one: Final-13682 per solve 78.5 ms
+  // with one arc, 46.9 with two, 36.5 with three, 48.0 with four.
+  int n_arcs = nT >= 256 ? 3 : 1;
+  if (const char* ea = getenv("MIBA_SPARSE_ARCS")) { const int v = atoi(ea); if (v >= 1 && v <= 4) n_arcs = v; }
+  if (nT < 8 * n_arcs) n_arcs = 1;
+  std::vector<int8_t> part(nT, 0);   // arc of a tile row; n_arcs = separator
+  if (n_arcs > 1) {
+    auto arc_of = [&](int v) { return (int)std::min<int64_t>(n_arcs - 1, (int64_t)v * n_arcs / nT); };
+    int n_sep = 0;
+    for (int v = 0; v < nT; ++v) {
+      const int av = arc_of(v);
+      const uint64_t* row = &adj[(size_t)v * nW];
+      bool mark = false, past = false;
+      for (size_t w = 0; w < nW && !mark && !past; ++w)
+        for (uint64_t m = row[w]; m; m &= m - 1) {
+          const int u = (int)(64 * w + __builtin_ctzll(m));
+          if (u >= v) { past = true; break; }
+          if (part[u] != n_arcs && arc_of(u) != av) { mark = true; break; }
+        }
+      part[v] = (int8_t)(mark ? n_arcs : av);
+      n_sep += mark;
+    }
+    if (3 * n_sep > nT) {
+      if (h->cfg.log_level > 0) fprintf(stderr, "[miba] tile graph: %d of %d tile rows in the separator of %d arcs: not dissected\n", n_sep, nT, n_arcs);
+      n_arcs = 1;
+      std::fill(part.begin(), part.end(), 0);
+    }
+  }
+  int interior_left = 0;
+  for (int v = 0; v < nT; ++v) interior_left += part[v] != n_arcs || n_arcs == 1;
+
+  // minimum degree on the tile graph (ties: the lowest tile row, which keeps a banded problem banded); separator rows only after
+  // every interior row
   auto popcnt_row = [&](int v) { int c = 0; for (size_t w = 0; w < nW; ++w) c += __builtin_popcountll(adj[(size_t)v * nW + w]); return c; };
   std::vector<int32_t> deg(nT), pos(nT, -1), grp(nT);
   for (int v = 0; v < nT; ++v) deg[v] = popcnt_row(v);
@@ -1308,9 +1360,10 @@ int sparse_symbolic(miba_handle h) {
   for (int k = 0; k < nT; ++k) {
     int v = -1;
     for (int u = 0; u < nT; ++u)
-      if (pos[u] < 0 && (v < 0 || deg[u] < deg[v])) v = u;
+      if (pos[u] < 0 && (interior_left == 0 || n_arcs == 1 || part[u] != n_arcs) && (v < 0 || deg[u] < deg[v])) v = u;
     pos[v] = k;
     grp[k] = v;
+    if (interior_left > 0) --interior_left;
     std::vector<int32_t>& nb = col_nodes[k];
     const uint64_t* av = &adj[(size_t)v * nW];
     for (size_t w = 0; w < nW; ++w)
@@ -1326,6 +1379,24 @@ int sparse_symbolic(miba_handle h) {
     }
   }
   std::vector<uint64_t>().swap(adj);
+  // the steps of one arc side by side in the order (a stable regrouping: rows of different arcs do not interact, so the fill is
+  // the same), the separator's steps last
+  std::vector<int32_t> arc_start(n_arcs + 1, nT);
+  if (n_arcs > 1) {
+    std::vector<int32_t> grp2(nT);
+    std::vector<std::vector<int32_t>> nodes2(nT);
+    int at = 0;
+    for (int a = 0; a <= n_arcs; ++a) {
+      arc_start[a] = at;
+      for (int k = 0; k < nT; ++k)
+        if (part[grp[k]] == a) { grp2[at] = grp[k]; nodes2[at].swap(col_nodes[k]); ++at; }
+    }
+    grp.swap(grp2);
+    col_nodes.swap(nodes2);
+    for (int k = 0; k < nT; ++k) pos[grp[k]] = k;
+  } else arc_start[0] = 0;
+  const int sep0 = arc_start[n_arcs];          // first separator column (nT: none)
+  const int nS = nT - sep0;
 
   // slots: the diagonal tile of tile row p is slot p, the tiles below the diagonal follow column by column, then the
   // right-hand-side tile of every column
@@ -1353,6 +1424,39 @@ int sparse_symbolic(miba_handle h) {
     map[(size_t)nT * nT + k] = (int32_t)(n_mat + k);
   }
   col_ptr[nT] = (int64_t)col_rows.size();
+  // private tiles of the arcs: every (row, column) pair of an arc's column whose column lies in the separator
+  std::vector<int32_t> smap, merge_ptr, merge_src, merge_dst;
+  int64_t n_priv = 0;
+  if (n_arcs > 1) {
+    smap.assign((size_t)n_arcs * (nS + 1) * nS, -1);
+    std::vector<std::pair<int32_t, int32_t>> contrib;   // (destination slot, private slot)
+    for (int a = 0; a < n_arcs; ++a) {
+      int32_t* sm = smap.data() + (size_t)a * (nS + 1) * nS;
+      for (int k = arc_start[a]; k < arc_start[a + 1]; ++k) {
+        const int32_t* rows = col_rows.data() + col_ptr[k] + 1;   // below the diagonal, ascending, the right-hand-side row (nT) last
+        const int m = (int)(col_ptr[k + 1] - col_ptr[k]) - 1;
+        int j0 = 0;
+        while (j0 < m && rows[j0] < sep0) ++j0;
+        for (int J = j0; J < m; ++J) {
+          if (rows[J] >= nT) break;
+          for (int I = J; I < m; ++I) {
+            int32_t& slot = sm[(size_t)(rows[I] - sep0) * nS + (rows[J] - sep0)];
+            if (slot < 0) {
+              slot = (int32_t)(n_mat + nT + n_priv++);
+              contrib.push_back({map[(size_t)rows[I] * nT + rows[J]], slot});
+            }
+          }
+        }
+      }
+    }
+    if (2 * (int64_t)nT + n_off + n_priv > max_tiles) return MIBA_OK;   // does not fit
+    std::stable_sort(contrib.begin(), contrib.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first < y.first; });
+    for (size_t i = 0; i < contrib.size(); ++i) {
+      if (i == 0 || contrib[i].first != contrib[i - 1].first) { merge_ptr.push_back((int32_t)i); merge_dst.push_back(contrib[i].first); }
+      merge_src.push_back(contrib[i].second);
+    }
+    merge_ptr.push_back((int32_t)contrib.size());
+  }
   std::vector<int32_t> row_cols, row_slots;
   std::vector<int64_t> row_ptr(nT + 1, 0);
   std::vector<int32_t> row_last(nT, -1);
@@ -1365,7 +1469,13 @@ int sparse_symbolic(miba_handle h) {
 
   int rc;
 #define SP_ALLOC(ptr, n) if ((rc = dev_alloc(h, &ptr, (size_t)(n)))) return rc
-  SP_ALLOC(h->d_sp_tiles, (size_t)(n_mat + nT) * 4096);
+  SP_ALLOC(h->d_sp_tiles, (size_t)(n_mat + nT + n_priv) * 4096);
+  if (n_arcs > 1) {
+    SP_ALLOC(h->d_sp_smap, smap.size());
+    SP_ALLOC(h->d_sp_merge_ptr, merge_ptr.size());
+    SP_ALLOC(h->d_sp_merge_src, merge_src.size() ? merge_src.size() : 1);
+    SP_ALLOC(h->d_sp_merge_dst, merge_dst.size() ? merge_dst.size() : 1);
+  }
   SP_ALLOC(h->d_sp_Ldiag, (size_t)nT * 4096);   // W = L^-T of every diagonal tile
   SP_ALLOC(h->d_sp_y, (size_t)nT * 64);
   SP_ALLOC(h->d_sp_x, (size_t)nT * 64);
@@ -1390,6 +1500,25 @@ int sparse_symbolic(miba_handle h) {
   h->sp_row_last.swap(row_last);
   h->sp_nT = nT;
   h->sp_n_mat = n_mat;
+  h->sp_n_arcs = n_arcs;
+  h->sp_arc.assign(arc_start.begin(), arc_start.end());
+  h->sp_n_priv = n_priv;
+  h->sp_n_merge = (int32_t)merge_dst.size();
+  h->sp_fill_tiles = n_off;
+  if (n_arcs > 1) {
+    if ((rc = upload(h, h->d_sp_smap, smap.data(), smap.size()))) return rc;
+    if ((rc = upload(h, h->d_sp_merge_ptr, merge_ptr.data(), merge_ptr.size()))) return rc;
+    if (!merge_src.empty() && (rc = upload(h, h->d_sp_merge_src, merge_src.data(), merge_src.size()))) return rc;
+    if (!merge_dst.empty() && (rc = upload(h, h->d_sp_merge_dst, merge_dst.data(), merge_dst.size()))) return rc;
+    for (int q = 0; q < 3; ++q) {
+      if (!h->sp_st[q]) HIPCHK(h, hipStreamCreateWithFlags(&h->sp_st[q], hipStreamNonBlocking));
+      if (!h->sp_ev_join[q]) HIPCHK(h, hipEventCreateWithFlags(&h->sp_ev_join[q], hipEventDisableTiming));
+    }
+    if (!h->sp_ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->sp_ev_fork, hipEventDisableTiming));
+  }
+  if (h->cfg.log_level > 0 || getenv("MIBA_SPARSE_DEBUG"))
+    fprintf(stderr, "[miba] tile factorisation: %d tile rows, %lld tiles below the diagonal after fill, %d arc(s), %d separator rows, %lld private tiles\n",
+            nT, (long long)n_off, n_arcs, nS, (long long)n_priv);
   if (!h->dense_plan_tried && (rc = dense_plan(h))) return rc;
   h->sparse_state = 1;
   return MIBA_OK;
@@ -1407,26 +1536,74 @@ int sparse_solve(miba_handle h, int* status) {
   hipLaunchKernelGGL(k_tchol_pad, dim3(nb64), dim3(256), 0, h->st, h->n_cam, nT, T, (const int32_t*)h->d_sp_grp);
   hipLaunchKernelGGL(k_tchol_rhs, dim3(nb64), dim3(256), 0, h->st, h->n_cam, nT, (const double*)h->d_rhs, T, (int)n_mat, (const int32_t*)h->d_sp_grp);
   HIPCHK(h, hipMemsetAsync(h->d_dflag, 0, sizeof(int32_t), h->st));
-  for (int k = 0; k < nT; ++k) {
+  const int n_arcs = h->sp_n_arcs;
+  const int sep0 = h->sp_arc[n_arcs];
+  // the two launches of column step k on stream st; an arc's column sends its separator updates to the arc's private tiles
+  auto column = [&](int k, hipStream_t st, const int32_t* smap) {
     const int64_t c0 = h->sp_col_ptr[k];
     const int cnt = (int)(h->sp_col_ptr[k + 1] - c0);   // diagonal, tiles below it, right-hand side
     double* W = h->d_sp_Ldiag + (size_t)k * 4096;
     const int m = cnt - 1;   // tiles below the diagonal, the right-hand-side tile among them
-    hipLaunchKernelGGL(k_tchol_col, dim3(m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_slots + c0), W, (int*)h->d_dflag);
+    hipLaunchKernelGGL(k_tchol_col, dim3(m), dim3(256), 0, st, T, (const int32_t*)(h->d_sp_col_slots + c0), W, (int*)h->d_dflag);
     if (m > 1)
-      hipLaunchKernelGGL(k_tchol_update, dim3(m, m), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_col_rows + c0 + 1),
-                         (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const int32_t*)h->d_sp_map, nT);
-  }
-  hipLaunchKernelGGL(k_tchol_gety, dim3(nb64), dim3(256), 0, h->st, nT, (const double*)T, (int)n_mat, h->d_sp_y);
-  int have_x = 0;
-  for (int k = nT - 1; k >= 0; --k) {
+      hipLaunchKernelGGL(k_tchol_update, dim3(m, m), dim3(256), 0, st, T, (const int32_t*)(h->d_sp_col_rows + c0 + 1),
+                         (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const int32_t*)h->d_sp_map, nT, smap, sep0);
+  };
+  // backward step of tile row k on stream st
+  auto backward = [&](int k, hipStream_t st, int& have_x) {
     const int64_t r0 = h->sp_row_ptr[k];
     const int nr = (int)(h->sp_row_ptr[k + 1] - r0);
     // the tiles of a row are listed by ascending column: the last one is (k, k - 1) if that tile exists
     const int ahead = (nr > 0 && h->sp_row_last[k] == k - 1) ? nr - 1 : -1;
-    hipLaunchKernelGGL(k_tchol_bwd, dim3(nr > 0 ? nr : 1), dim3(kNB), 0, h->st, (const double*)T, k, nr, (const int32_t*)(h->d_sp_row_cols + r0),
+    hipLaunchKernelGGL(k_tchol_bwd, dim3(nr > 0 ? nr : 1), dim3(kNB), 0, st, (const double*)T, k, nr, (const int32_t*)(h->d_sp_row_cols + r0),
                        (const int32_t*)(h->d_sp_row_slots + r0), (const double*)h->d_sp_Ldiag, h->d_sp_y, h->d_sp_x, have_x, ahead);
     have_x = ahead >= 0;
+  };
+  // arc a runs on the main stream (a = 0) or on one of the extra streams; fork / join by events
+  auto arc_stream = [&](int a) { return a == 0 ? h->st : h->sp_st[(a - 1) % 3]; };
+  auto fork = [&]() -> int {
+    HIPCHK(h, hipEventRecord(h->sp_ev_fork, h->st));
+    for (int q = 0; q < 3 && q < n_arcs - 1; ++q) HIPCHK(h, hipStreamWaitEvent(h->sp_st[q], h->sp_ev_fork, 0));
+    return MIBA_OK;
+  };
+  auto join = [&]() -> int {
+    for (int q = 0; q < 3 && q < n_arcs - 1; ++q) {
+      HIPCHK(h, hipEventRecord(h->sp_ev_join[q], h->sp_st[q]));
+      HIPCHK(h, hipStreamWaitEvent(h->st, h->sp_ev_join[q], 0));
+    }
+    return MIBA_OK;
+  };
+  if (n_arcs > 1) {
+    if (h->sp_n_priv) HIPCHK(h, hipMemsetAsync(T + (size_t)(n_mat + nT) * 4096, 0, (size_t)h->sp_n_priv * 4096 * sizeof(double), h->st));
+    if ((rc = fork())) return rc;
+    const size_t smap_stride = (size_t)(nT - sep0 + 1) * (nT - sep0);
+    // (round-robin over the arcs' columns, so that the launches of all streams are enqueued side by side)
+    std::vector<int> at(h->sp_arc.begin(), h->sp_arc.begin() + n_arcs);
+    for (bool any = true; any;) {
+      any = false;
+      for (int a = 0; a < n_arcs; ++a)
+        if (at[a] < h->sp_arc[a + 1]) { column(at[a]++, arc_stream(a), h->d_sp_smap + a * smap_stride); any = true; }
+    }
+    if ((rc = join())) return rc;
+    if (h->sp_n_merge)
+      hipLaunchKernelGGL(k_tchol_merge, dim3(h->sp_n_merge), dim3(256), 0, h->st, T, (const int32_t*)h->d_sp_merge_ptr, (const int32_t*)h->d_sp_merge_src,
+                         (const int32_t*)h->d_sp_merge_dst);
+  }
+  for (int k = (n_arcs > 1 ? sep0 : 0); k < nT; ++k) column(k, h->st, nullptr);
+  hipLaunchKernelGGL(k_tchol_gety, dim3(nb64), dim3(256), 0, h->st, nT, (const double*)T, (int)n_mat, h->d_sp_y);
+  int have_x = 0;
+  for (int k = nT - 1; k >= (n_arcs > 1 ? sep0 : 0); --k) backward(k, h->st, have_x);
+  if (n_arcs > 1) {
+    // below the separator the rows of an arc touch only columns of the arc
+    if ((rc = fork())) return rc;
+    std::vector<int> at(n_arcs), hx(n_arcs, 0);
+    for (int a = 0; a < n_arcs; ++a) at[a] = h->sp_arc[a + 1] - 1;
+    for (bool any = true; any;) {
+      any = false;
+      for (int a = 0; a < n_arcs; ++a)
+        if (at[a] >= h->sp_arc[a]) { backward(at[a]--, arc_stream(a), hx[a]); any = true; }
+    }
+    if ((rc = join())) return rc;
   }
   hipLaunchKernelGGL(k_tchol_unperm, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, (const double*)h->d_sp_x,
                      (const int32_t*)h->d_sp_pos, h->d_px);
@@ -1867,6 +2044,11 @@ int miba_destroy(miba_handle h) {
   }
   if (h->ev_state) (void)hipEventDestroy(h->ev_state);
   if (h->st2) { (void)hipStreamSynchronize(h->st2); (void)hipStreamDestroy(h->st2); }
+  for (int q = 0; q < 3; ++q) {
+    if (h->sp_st[q]) { (void)hipStreamSynchronize(h->sp_st[q]); (void)hipStreamDestroy(h->sp_st[q]); }
+    if (h->sp_ev_join[q]) (void)hipEventDestroy(h->sp_ev_join[q]);
+  }
+  if (h->sp_ev_fork) (void)hipEventDestroy(h->sp_ev_fork);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   if (h->st) (void)hipStreamDestroy(h->st);

@@ -169,15 +169,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // Column step k, second launch, trailing update: tile (r_I, r_J) -= L(r_I, k) L(r_J, k)' for the tiles I >= J below the diagonal of the
-// column (rows[] / slots[] list them, diagonal excluded); the destination comes from the tile map (symbolic fill guarantees it)
+// column (rows[] / slots[] list them, diagonal excluded); the destination comes from the tile map (symbolic fill guarantees it).
+// A column of an arc (smap != null; the arcs of the dissected order run side by side on several streams) sends the updates whose
+// column lies in the separator (rJ >= sep0) to the arc's private tiles instead: smap[(rI - sep0) * (nT - sep0) + (rJ - sep0)],
+// zero before the factorisation and added to the matrix by k_tchol_merge once all arcs are done.
 __global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles, const int32_t* __restrict__ rows,
-                                                      const int32_t* __restrict__ slots, const int32_t* __restrict__ map, int nT) {
+                                                      const int32_t* __restrict__ slots, const int32_t* __restrict__ map, int nT,
+                                                      const int32_t* __restrict__ smap, int sep0) {
   __shared__ double bt[kNB][kNB + 1];
   const int I = blockIdx.y, J = blockIdx.x;
   if (J > I) return;
   const int rI = rows[I], rJ = rows[J];
   if (rJ >= nT) return;                       // the right-hand-side row is never a column
-  const int32_t dslot = map[(size_t)rI * nT + rJ];
+  const int32_t dslot = (smap != nullptr && rJ >= sep0) ? smap[(size_t)(rI - sep0) * (nT - sep0) + (rJ - sep0)] : map[(size_t)rI * nT + rJ];
   if (dslot < 0) return;                      // cannot happen after symbolic fill; never write through a bad slot
   const double* A = tiles + (size_t)slots[I] * 4096;
   const double* B = tiles + (size_t)slots[J] * 4096;
@@ -209,6 +213,28 @@ __global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] = -c[nt][reg];
   }
+}
+
+// the arcs' private tiles into the matrix: workgroup d adds the private tiles src[ptr[d]] .. src[ptr[d + 1] - 1] (in that order:
+// arcs ascending) to tile dst[d]
+__global__ __launch_bounds__(256) void k_tchol_merge(double* __restrict__ tiles, const int32_t* __restrict__ ptr, const int32_t* __restrict__ src,
+                                                     const int32_t* __restrict__ dst) {
+  const int d = blockIdx.x, tid = threadIdx.x;
+  const int p0 = ptr[d], p1 = ptr[d + 1];
+  double* D = tiles + (size_t)dst[d] * 4096;
+  double v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = D[tid + 256 * q];
+  for (int p = p0; p < p1; ++p) {
+    const double* S = tiles + (size_t)src[p] * 4096;
+    double w[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q] = S[tid + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] += w[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) D[tid + 256 * q] = v[q];
 }
 
 // right-hand side into row 0 of the tiles of the extra tile row (slots rhs0 .. rhs0 + nT - 1, cleared beforehand); tile row p holds
