@@ -1311,90 +1311,16 @@ int sparse_symbolic(miba_handle h) {
 
   const int64_t max_tiles = (int64_t)(free_all / 2 / (4096 * sizeof(double)));
 
-  // Dissection of the tile graph into arcs that can be factored side by side (the elimination order of a band is a chain: at
-  // Final-13682 1,955 tile columns of 29 us each).  The tile rows are cut by index into n_arcs equal ranges; an edge between two
-  // ranges puts its higher end into the separator (rows ascending: a valid cover of the crossing edges; on a band these are the
-  // first rows behind every cut, on a ring also the last rows, which close it).  Interiors of different arcs then share no edge, and
-  // eliminating an interior row creates fill only inside its arc and towards the separator: the arcs' columns are independent of
-  // each other, the separator rows come last.  Only camera numberings with locality (what BAL files and the stand-in have) dissect
-  // this way; if the separator takes more than a third of the rows the order stays plain minimum degree on one stream.
-  // MIBA_SPARSE_ARCS=1..4 overrides the number of arcs (tests, measurements).  Default three from 256 tile rows up: a process has four
-  // hardware queues, and with four arcs (main stream + three) two of the streams end up sharing one: Final-13682 per solve 78.5 ms
-  // with one arc, 46.9 with two, 36.5 with three, 48.0 with four.
+  // Elimination order (order_tile_graph, miba_plan.hpp): the tile graph dissected into arcs that can be factored side by side, minimum
+  // degree inside.  MIBA_SPARSE_ARCS=1..4 overrides the number of arcs (tests, measurements).  Default three from 256 tile rows up: a
+  // process has four hardware queues, and with four arcs (main stream + three) two of the streams end up sharing one: Final-13682 per
+  // solve 78.5 ms with one arc, 46.9 with two, 36.5 with three, 48.0 with four.
   int n_arcs = nT >= 256 ? 3 : 1;
   if (const char* ea = getenv("MIBA_SPARSE_ARCS")) { const int v = atoi(ea); if (v >= 1 && v <= 4) n_arcs = v; }
-  if (nT < 8 * n_arcs) n_arcs = 1;
-  std::vector<int8_t> part(nT, 0);   // arc of a tile row; n_arcs = separator
-  if (n_arcs > 1) {
-    auto arc_of = [&](int v) { return (int)std::min<int64_t>(n_arcs - 1, (int64_t)v * n_arcs / nT); };
-    int n_sep = 0;
-    for (int v = 0; v < nT; ++v) {
-      const int av = arc_of(v);
-      const uint64_t* row = &adj[(size_t)v * nW];
-      bool mark = false, past = false;
-      for (size_t w = 0; w < nW && !mark && !past; ++w)
-        for (uint64_t m = row[w]; m; m &= m - 1) {
-          const int u = (int)(64 * w + __builtin_ctzll(m));
-          if (u >= v) { past = true; break; }
-          if (part[u] != n_arcs && arc_of(u) != av) { mark = true; break; }
-        }
-      part[v] = (int8_t)(mark ? n_arcs : av);
-      n_sep += mark;
-    }
-    if (3 * n_sep > nT) {
-      if (h->cfg.log_level > 0) fprintf(stderr, "[miba] tile graph: %d of %d tile rows in the separator of %d arcs: not dissected\n", n_sep, nT, n_arcs);
-      n_arcs = 1;
-      std::fill(part.begin(), part.end(), 0);
-    }
-  }
-  int interior_left = 0;
-  for (int v = 0; v < nT; ++v) interior_left += part[v] != n_arcs || n_arcs == 1;
-
-  // minimum degree on the tile graph (ties: the lowest tile row, which keeps a banded problem banded); separator rows only after
-  // every interior row
-  auto popcnt_row = [&](int v) { int c = 0; for (size_t w = 0; w < nW; ++w) c += __builtin_popcountll(adj[(size_t)v * nW + w]); return c; };
-  std::vector<int32_t> deg(nT), pos(nT, -1), grp(nT);
-  for (int v = 0; v < nT; ++v) deg[v] = popcnt_row(v);
-  std::vector<std::vector<int32_t>> col_nodes(nT);
+  std::vector<int32_t> pos, grp, arc_start;
+  std::vector<std::vector<int32_t>> col_nodes;
   int64_t n_off = 0;
-  for (int k = 0; k < nT; ++k) {
-    int v = -1;
-    for (int u = 0; u < nT; ++u)
-      if (pos[u] < 0 && (interior_left == 0 || n_arcs == 1 || part[u] != n_arcs) && (v < 0 || deg[u] < deg[v])) v = u;
-    pos[v] = k;
-    grp[k] = v;
-    if (interior_left > 0) --interior_left;
-    std::vector<int32_t>& nb = col_nodes[k];
-    const uint64_t* av = &adj[(size_t)v * nW];
-    for (size_t w = 0; w < nW; ++w)
-      for (uint64_t m = av[w]; m; m &= m - 1) nb.push_back((int32_t)(64 * w + __builtin_ctzll(m)));
-    n_off += (int64_t)nb.size();
-    if (2 * (int64_t)nT + n_off > max_tiles) return MIBA_OK;   // does not fit: sparse_state stays -1
-    for (int32_t u : nb) {
-      uint64_t* au = &adj[(size_t)u * nW];
-      for (size_t w = 0; w < nW; ++w) au[w] |= av[w];
-      au[v >> 6] &= ~((uint64_t)1 << (v & 63));
-      au[u >> 6] &= ~((uint64_t)1 << (u & 63));
-      deg[u] = popcnt_row(u);
-    }
-  }
-  std::vector<uint64_t>().swap(adj);
-  // the steps of one arc side by side in the order (a stable regrouping: rows of different arcs do not interact, so the fill is
-  // the same), the separator's steps last
-  std::vector<int32_t> arc_start(n_arcs + 1, nT);
-  if (n_arcs > 1) {
-    std::vector<int32_t> grp2(nT);
-    std::vector<std::vector<int32_t>> nodes2(nT);
-    int at = 0;
-    for (int a = 0; a <= n_arcs; ++a) {
-      arc_start[a] = at;
-      for (int k = 0; k < nT; ++k)
-        if (part[grp[k]] == a) { grp2[at] = grp[k]; nodes2[at].swap(col_nodes[k]); ++at; }
-    }
-    grp.swap(grp2);
-    col_nodes.swap(nodes2);
-    for (int k = 0; k < nT; ++k) pos[grp[k]] = k;
-  } else arc_start[0] = 0;
+  if (!order_tile_graph(adj, nT, n_arcs, max_tiles, h->cfg.log_level, n_arcs, grp, pos, col_nodes, arc_start, n_off)) return MIBA_OK;   // does not fit: sparse_state stays -1
   const int sep0 = arc_start[n_arcs];          // first separator column (nT: none)
   const int nS = nT - sep0;
 
@@ -2095,6 +2021,32 @@ int miba_plan_product_stats(const miba_problem* p, double* out10) {
   out8[0] = ok ? 1.0 : 0.0;
   out8[1] = (double)S.n_obs; out8[2] = (double)S.n_entries; out8[3] = (double)S.n_sub; out8[4] = (double)S.n_seg;
   out8[5] = S.pt_mult; out8[6] = S.cam_mult; out8[7] = (double)n_giant_obs; out8[8] = S.rd_extra; out8[9] = S.at_extra;
+  return MIBA_OK;
+}
+
+int miba_plan_tile_order(int32_t n_rows, const int32_t* eu, const int32_t* ev, int64_t n_edges, int32_t n_arcs, int32_t* pos_out,
+                         int32_t* arc_start_out, int32_t* n_arcs_out, int64_t* fill_tiles) {
+  if (n_rows < 1 || n_rows > 32768 || n_edges < 0 || (n_edges && (!eu || !ev)) || !pos_out || !arc_start_out || n_arcs < 1 || n_arcs > 4)
+    return fail(nullptr, MIBA_ERR_INVALID, "bad tile graph");
+  const size_t nW = ((size_t)n_rows + 63) / 64;
+  std::vector<uint64_t> adj((size_t)n_rows * nW, 0);
+  for (int64_t i = 0; i < n_edges; ++i) {
+    const int32_t u = eu[i], v = ev[i];
+    if (u < 0 || v < 0 || u >= n_rows || v >= n_rows) return fail(nullptr, MIBA_ERR_INVALID, "edge %lld out of range", (long long)i);
+    if (u == v) continue;
+    adj[(size_t)u * nW + (v >> 6)] |= (uint64_t)1 << (v & 63);
+    adj[(size_t)v * nW + (u >> 6)] |= (uint64_t)1 << (u & 63);
+  }
+  int na = n_arcs;
+  std::vector<int32_t> grp, pos, arc_start;
+  std::vector<std::vector<int32_t>> col_nodes;
+  int64_t n_off = 0;
+  if (!order_tile_graph(adj, n_rows, n_arcs, (int64_t)1 << 40, 0, na, grp, pos, col_nodes, arc_start, n_off))
+    return fail(nullptr, MIBA_ERR_LIMIT, "tile graph too large");
+  for (int32_t v = 0; v < n_rows; ++v) pos_out[v] = pos[v];
+  for (int a = 0; a < 5; ++a) arc_start_out[a] = arc_start[std::min(a, na)];
+  if (n_arcs_out) *n_arcs_out = na;
+  if (fill_tiles) *fill_tiles = n_off;
   return MIBA_OK;
 }
 

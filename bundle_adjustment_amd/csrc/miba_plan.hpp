@@ -555,6 +555,105 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
 }
 
 
+// ---- elimination order of the tile graph of the exact solve (sparse_symbolic in miba.hip; host only) ----------------------------
+// adj: nT rows of nW = ceil(nT / 64) words, bit u of row v set when tile rows u and v share an entry (no diagonal); destroyed.
+// Out: the order (grp[k] = tile row eliminated at step k, pos = its inverse), per step the rows below the diagonal after fill
+// (col_nodes, as tile rows), their total n_off, the number of arcs the order was dissected into and the first step of every arc
+// (arc_start[n_arcs] = first separator step, nT when there is none).  false: more than max_tiles tiles.
+inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int n_arcs_wanted, const int64_t max_tiles, const int log_level,
+                             int& n_arcs_out, std::vector<int32_t>& grp_out, std::vector<int32_t>& pos_out,
+                             std::vector<std::vector<int32_t>>& col_nodes_out, std::vector<int32_t>& arc_start_out, int64_t& n_off_out) {
+  const size_t nW = ((size_t)nT + 63) / 64;
+  int n_arcs = n_arcs_wanted;
+  // Dissection of the tile graph into arcs that can be factored side by side (the elimination order of a band is a chain: at
+  // Final-13682 1,955 tile columns of 29 us each).  The tile rows are cut by index into n_arcs equal ranges; an edge between two
+  // ranges puts its higher end into the separator (rows ascending: a valid cover of the crossing edges; on a band these are the
+  // first rows behind every cut, on a ring also the last rows, which close it).  Interiors of different arcs then share no edge, and
+  // eliminating an interior row creates fill only inside its arc and towards the separator: the arcs' columns are independent of
+  // each other, the separator rows come last.  Only camera numberings with locality (what BAL files and the stand-in have) dissect
+  // this way; if the separator takes more than a third of the rows the order stays plain minimum degree on one stream.
+  if (nT < 8 * n_arcs) n_arcs = 1;
+  std::vector<int8_t> part(nT, 0);   // arc of a tile row; n_arcs = separator
+  if (n_arcs > 1) {
+    auto arc_of = [&](int v) { return (int)std::min<int64_t>(n_arcs - 1, (int64_t)v * n_arcs / nT); };
+    int n_sep = 0;
+    for (int v = 0; v < nT; ++v) {
+      const int av = arc_of(v);
+      const uint64_t* row = &adj[(size_t)v * nW];
+      bool mark = false, past = false;
+      for (size_t w = 0; w < nW && !mark && !past; ++w)
+        for (uint64_t m = row[w]; m; m &= m - 1) {
+          const int u = (int)(64 * w + __builtin_ctzll(m));
+          if (u >= v) { past = true; break; }
+          if (part[u] != n_arcs && arc_of(u) != av) { mark = true; break; }
+        }
+      part[v] = (int8_t)(mark ? n_arcs : av);
+      n_sep += mark;
+    }
+    if (3 * n_sep > nT) {
+      if (log_level > 0) fprintf(stderr, "[miba] tile graph: %d of %d tile rows in the separator of %d arcs: not dissected\n", n_sep, nT, n_arcs);
+      n_arcs = 1;
+      std::fill(part.begin(), part.end(), 0);
+    }
+  }
+  int interior_left = 0;
+  for (int v = 0; v < nT; ++v) interior_left += part[v] != n_arcs || n_arcs == 1;
+
+  // minimum degree on the tile graph (ties: the lowest tile row, which keeps a banded problem banded); separator rows only after
+  // every interior row
+  auto popcnt_row = [&](int v) { int c = 0; for (size_t w = 0; w < nW; ++w) c += __builtin_popcountll(adj[(size_t)v * nW + w]); return c; };
+  std::vector<int32_t> deg(nT), pos(nT, -1), grp(nT);
+  for (int v = 0; v < nT; ++v) deg[v] = popcnt_row(v);
+  std::vector<std::vector<int32_t>> col_nodes(nT);
+  int64_t n_off = 0;
+  for (int k = 0; k < nT; ++k) {
+    int v = -1;
+    for (int u = 0; u < nT; ++u)
+      if (pos[u] < 0 && (interior_left == 0 || n_arcs == 1 || part[u] != n_arcs) && (v < 0 || deg[u] < deg[v])) v = u;
+    pos[v] = k;
+    grp[k] = v;
+    if (interior_left > 0) --interior_left;
+    std::vector<int32_t>& nb = col_nodes[k];
+    const uint64_t* av = &adj[(size_t)v * nW];
+    for (size_t w = 0; w < nW; ++w)
+      for (uint64_t m = av[w]; m; m &= m - 1) nb.push_back((int32_t)(64 * w + __builtin_ctzll(m)));
+    n_off += (int64_t)nb.size();
+    if (2 * (int64_t)nT + n_off > max_tiles) return false;   // does not fit
+    for (int32_t u : nb) {
+      uint64_t* au = &adj[(size_t)u * nW];
+      for (size_t w = 0; w < nW; ++w) au[w] |= av[w];
+      au[v >> 6] &= ~((uint64_t)1 << (v & 63));
+      au[u >> 6] &= ~((uint64_t)1 << (u & 63));
+      deg[u] = popcnt_row(u);
+    }
+  }
+  std::vector<uint64_t>().swap(adj);
+  // the steps of one arc side by side in the order (a stable regrouping: rows of different arcs do not interact, so the fill is
+  // the same), the separator's steps last
+  std::vector<int32_t> arc_start(n_arcs + 1, nT);
+  if (n_arcs > 1) {
+    std::vector<int32_t> grp2(nT);
+    std::vector<std::vector<int32_t>> nodes2(nT);
+    int at = 0;
+    for (int a = 0; a <= n_arcs; ++a) {
+      arc_start[a] = at;
+      for (int k = 0; k < nT; ++k)
+        if (part[grp[k]] == a) { grp2[at] = grp[k]; nodes2[at].swap(col_nodes[k]); ++at; }
+    }
+    grp.swap(grp2);
+    col_nodes.swap(nodes2);
+    for (int k = 0; k < nT; ++k) pos[grp[k]] = k;
+  } else arc_start[0] = 0;
+  n_arcs_out = n_arcs;
+  grp_out.swap(grp);
+  pos_out.swap(pos);
+  col_nodes_out.swap(col_nodes);
+  arc_start_out.swap(arc_start);
+  n_off_out = n_off;
+  return true;
+}
+
+
 // ---- camera-major sub-tile layout of the product kernel (K3, miba_mf2.hpp) ------------------------------------------
 // The product's per-observation work wants two things at once: the camera record (24 doubles) and a place to add nine
 // camera-side sums, and the point (3 doubles) and a place to add three point-side sums.  The point-major wavelets of the

@@ -27,7 +27,7 @@ EXPORTS = [
     "miba_default_options", "miba_create", "miba_create_multi", "miba_destroy", "miba_last_error", "miba_comm_unique_id",
     "miba_set_problem", "miba_set_state", "miba_get_state", "miba_evaluate", "miba_solve",
     "miba_get_iterations", "miba_linear_step", "miba_get_kernel_times", "miba_reset_kernel_times",
-    "miba_plan_shards", "miba_plan_point_owner", "miba_plan_product_stats", "miba_time_matvec", "miba_set_constant_blocks",
+    "miba_plan_shards", "miba_plan_point_owner", "miba_plan_product_stats", "miba_plan_tile_order", "miba_time_matvec", "miba_set_constant_blocks",
     "miba_get_reduced_system", "miba_dense_spd_solve", "miba_dense_spd_solve_static",
 ]
 STATIC_SOLVE_MAX_N = 1024   # MIBA_STATIC_SOLVE_MAX_N of include/miba.h
@@ -177,6 +177,20 @@ def plan_point_owner(n_cam, n_pt, obs_cam, obs_pt, obs_xy, world_size):
     if rc != 0:
         raise MibaError("miba_plan_point_owner rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
     return owner
+
+
+def plan_tile_order(n_rows, edges_u, edges_v, n_arcs):
+    """Host-only: elimination order of a tile graph as the exact solve's symbolic phase computes it (miba_plan_tile_order)."""
+    eu = np.ascontiguousarray(edges_u, dtype=np.int32)
+    ev = np.ascontiguousarray(edges_v, dtype=np.int32)
+    pos = np.zeros(n_rows, dtype=np.int32)
+    arc = np.zeros(5, dtype=np.int32)
+    na, fill = C.c_int32(0), C.c_int64(0)
+    rc = lib().miba_plan_tile_order(C.c_int32(n_rows), _ip(eu), _ip(ev), C.c_int64(eu.size), C.c_int32(n_arcs), _ip(pos), _ip(arc),
+                                    C.byref(na), C.byref(fill))
+    if rc != 0:
+        raise MibaError("miba_plan_tile_order rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
+    return dict(pos=pos, arc_start=[int(a) for a in arc[:na.value + 1]], n_arcs=na.value, fill_tiles=fill.value)
 
 
 def plan_product_stats(n_cam, n_pt, obs_cam, obs_pt, obs_xy):

@@ -260,6 +260,9 @@ def test_kernel_times_report_the_shape_of_a_pcg_iteration_and_the_product_clock(
             os.environ.pop("MIBA_K3", None)
         else:
             os.environ["MIBA_K3"] = old
-    assert kt["pcg_launches"] == 2 and kt["pcg_exchange"] == 0
+    # (the environment matrix of tools/gpu_env_matrix.sh runs this under the knobs that change the shape)
+    forced = os.environ.get("MIBA_FORCE_RCCL") == "1"
+    split = os.environ.get("MIBA_TAIL_SPLIT") == "1"
+    assert kt["pcg_launches"] == (4 if split else 3 if forced else 2) and kt["pcg_exchange"] == (1 if forced else 0)
     assert kt["product_layout"] == 1
     assert 500.0 < kt["product_clock_mhz"] < 3000.0, kt["product_clock_mhz"]

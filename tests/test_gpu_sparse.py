@@ -92,7 +92,10 @@ def test_dissected_order_equals_dense(shape, arcs):
         a2 = _step(pr, cams0, pts0, 1e4, "sparse")
     b = _step(pr, cams0, pts0, 1e4, "dense")
     assert a["n_cg"] == 1 and b["n_cg"] == 1
-    assert np.array_equal(a["y_cam"], a2["y_cam"])   # fixed merge order: the same bits from run to run
+    if os.environ.get("MIBA_DENSE_PLAN") == "0":     # (assembly with global atomics: S itself differs in the last bits from run to run)
+        assert rel(a["y_cam"], a2["y_cam"]) <= 1e-10
+    else:
+        assert np.array_equal(a["y_cam"], a2["y_cam"])   # fixed merge order: the same bits from run to run
     assert rel(a["y_cam"], b["y_cam"]) <= 1e-9, rel(a["y_cam"], b["y_cam"])
     assert rel(a["y_pt"], b["y_pt"]) <= 1e-9
     assert abs(a["model_cost_change"] - b["model_cost_change"]) <= 1e-11 * abs(b["model_cost_change"])

@@ -208,3 +208,73 @@ def test_product_layout_is_a_permutation(chunks, monkeypatch):
     assert st["n_obs"] == int(valid.sum()) - giant_obs
     assert st["n_entries"] >= st["n_obs"] and st["n_seg"] * 4 >= st["n_obs"]
     assert 1.0 <= st["cam_mult"] <= 8.0 and st["pt_mult"] >= 1.0
+
+
+def _band_ring(n, w, ring):
+    eu, ev = [], []
+    for v in range(n):
+        for d in range(1, w + 1):
+            u = v + d
+            if u < n:
+                eu.append(v); ev.append(u)
+            elif ring:
+                eu.append(v); ev.append(u - n)
+    return np.array(eu, np.int32), np.array(ev, np.int32)
+
+
+def _symbolic_fill(n, eu, ev, pos):
+    """independent restatement: eliminate in the given order, return the column patterns (as steps) and the fill count"""
+    order = np.argsort(pos)
+    adj = [set() for _ in range(n)]
+    for u, v in zip(eu.tolist(), ev.tolist()):
+        if u != v:
+            adj[u].add(v); adj[v].add(u)
+    done = np.zeros(n, bool)
+    cols, fill = [], 0
+    for v in order.tolist():
+        nb = [u for u in adj[v] if not done[u]]
+        cols.append(sorted(int(pos[u]) for u in nb))
+        fill += len(nb)
+        for a in nb:
+            adj[a].update(b for b in nb if b != a)
+        done[v] = True
+    return cols, fill
+
+
+@pytest.mark.parametrize("shape,n,w,arcs", [("ring", 400, 6, 3), ("band", 300, 4, 4), ("ring", 257, 9, 2), ("ring", 120, 5, 1)])
+def test_tile_order_dissects_bands_and_rings(shape, n, w, arcs):
+    """the exact solve's elimination order (csrc/miba_plan.hpp, order_tile_graph; what Ceres' ordering does behind ceres::Solve at
+    src/BundleAdjustment.cpp:108 for SPARSE_SCHUR): a permutation; the arcs' steps are contiguous and come before the separator's;
+    a column of one arc never holds a row of another arc (so the arcs can be factored side by side); the fill it reports is the fill
+    of an independent symbolic elimination in that order, and close to the undissected order's."""
+    eu, ev = _band_ring(n, w, shape == "ring")
+    r = miba.plan_tile_order(n, eu, ev, arcs)
+    pos, st = r["pos"], r["arc_start"]
+    assert sorted(pos.tolist()) == list(range(n))
+    assert r["n_arcs"] == arcs and len(st) == arcs + 1 and st[0] == 0 and all(a <= b for a, b in zip(st, st[1:])) and st[-1] <= n
+    cols, fill = _symbolic_fill(n, eu, ev, pos)
+    assert fill == r["fill_tiles"]
+    arc_of_step = lambda k: next((a for a in range(arcs) if st[a] <= k < st[a + 1]), arcs)   # arcs = separator
+    for k, rows in enumerate(cols):
+        a = arc_of_step(k)
+        for row in rows:
+            assert row > k
+            assert arc_of_step(row) in (a, arcs), (k, row)          # own arc or separator, never another arc
+    if arcs > 1:
+        assert 0 < n - st[-1] <= n // 3                             # a separator exists and is small
+        plain = miba.plan_tile_order(n, eu, ev, 1)
+        # (an arc carries the separator rows of its low end along, as the plain order of a RING carries the rows that close it: about
+        # the same fill on a ring, up to twice a plain band's)
+        assert r["fill_tiles"] <= (1.25 if shape == "ring" else 2.0) * plain["fill_tiles"]
+
+
+def test_tile_order_without_locality_is_not_dissected():
+    """a graph whose edges ignore the numbering has no small separator by index: one chain, plain minimum degree"""
+    rng = np.random.default_rng(4)
+    n = 200
+    eu = rng.integers(0, n, 1200).astype(np.int32)
+    ev = rng.integers(0, n, 1200).astype(np.int32)
+    r = miba.plan_tile_order(n, eu, ev, 3)
+    assert r["n_arcs"] == 1 and r["arc_start"] == [0, n]
+    cols, fill = _symbolic_fill(n, eu, ev, r["pos"])
+    assert fill == r["fill_tiles"]

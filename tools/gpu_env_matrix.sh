@@ -13,8 +13,12 @@ if [ -z "$SKIP_TILE_CHUNKS" ]; then
 run MIBA_TILE_CHUNKS=1 || exit 1
 run MIBA_TILE_CHUNKS=16 || exit 1
 fi
+if [ -z "$SKIP_DONE" ]; then
 run MIBA_POINT_ORDER=0 || exit 1
+fi
+if [ -z "$SKIP_DONE" ]; then
 run MIBA_FORCE_RCCL=1 || exit 1
+fi
 run MIBA_DENSE_PLAN=0 || exit 1
 run MIBA_DENSE_PLAN=host || exit 1
 run MIBA_DEVICE_PLAN=0 || exit 1
