@@ -794,16 +794,21 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
           for (const int32_t r : porder) {
             const int32_t n = pt_count_local[r];
             const size_t o = (size_t)poff[(size_t)(r - p)];
+            // cost of every bank pair at once (observation by observation: the inner loops run over contiguous counters and
+            // vectorise), then the first cheapest free one in the point's rotated order
+            int cost[32];
+            for (int c = 0; c < 32; ++c) cost[c] = 0;
+            for (int32_t i = 0; i < n; ++i) {
+              const int pl = place[o + i], lane = pl & 0xFF, step = (pl >> 8) & 3;
+              const int* rd = rd_cnt[(lane >> 5) * 4 + step];
+              const int* at = at_cnt[(lane >> 4) * 4 + step];
+              for (int c = 0; c < 16; ++c) { cost[c] += 9 * rd[c] + 6 * at[c]; cost[16 + c] += 9 * rd[16 + c] + 6 * at[c]; }
+            }
             int best = -1, best_cost = 1 << 30;
             for (int cc = 0; cc < 32; ++cc) {
               const int c = (cc + (int)(r - p)) & 31;
               if (free_per_color[c] >= 8) continue;
-              int cost = 0;
-              for (int32_t i = 0; i < n; ++i) {
-                const int pl = place[o + i], lane = pl & 0xFF, step = (pl >> 8) & 3;
-                cost += 9 * rd_cnt[(lane >> 5) * 4 + step][c] + 6 * at_cnt[(lane >> 4) * 4 + step][c & 15];
-              }
-              if (cost < best_cost) { best = c; best_cost = cost; if (!cost) break; }
+              if (cost[c] < best_cost) { best = c; best_cost = cost[c]; if (!best_cost) break; }
             }
             if (no_color) best = (int)(r - p) & 31;
             const int slot = best + 32 * free_per_color[best]++;
