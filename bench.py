@@ -262,8 +262,8 @@ def main():
             "flop_note": ("%.1f fp64 flop per observation (FMA = 2) counted from the kernel's ISA x %d observations" % (MF_CM_FLOP_PER_OBS, o_loc)) if cm_layout
                          else ("%.0f fp64 flop per padded slot counted from the kernel's ISA x %d slots" % (MF_FLOP_PER_SLOT, kt["n_slots"])),
             "traffic": rec3.get("traffic_bytes_per_launch"),
-            "traffic_source": (pmc_file + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of an earlier run of this kernel; "
-                               "a constant, not collected in this run)") if pmc_file else None,
+            "traffic_source": (pmc_file + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of an earlier run of this kernel, taken on commit %s; "
+                               "a constant, not collected in this run)" % pmc.get("commit", "?")) if pmc_file else None,
             "avg_launch_ms": k3_ms, "launches_timed": k3_n, "launches_in_timed_steps": k3_total,
             "timed_launches_that_returned_at_once": k3_skipped,
             "hbm": hbm_view,
