@@ -172,6 +172,7 @@ struct miba_handle_s {
   // camera-major sub-tile layout of the product (miba_mf2.hpp); k3_cm = 0: the point-major product (MIBA_K3=pm, tests / A-B)
   CmTile* d_cmt = nullptr; CmSub* d_cms = nullptr; uint2* d_cmi = nullptr; int4* d_cam64 = nullptr; uint8_t* d_cmslot = nullptr;
   int k3_cm = 1;
+  double2* d_oxy_cm = nullptr;   // measurements in the order of the camera-major entries (K4 over the sub-tiles, k_mf_backsub_cm)
   // camera-major copy of the local observations (K2-mf camera side): segments of one camera each
   int4* d_seg = nullptr; int32_t* d_cmo_pt = nullptr; double2* d_cmo_xy = nullptr; int32_t* d_cam_seg_off = nullptr;
   double* d_slabB = nullptr;
@@ -182,6 +183,7 @@ struct miba_handle_s {
   int n_cu = 1, dev_share = 1;                    // compute units of the device; ranks of this process that share it
   int tail_nb = 1, tail_n_vw = 0;                 // grid of pcg_tail: resident as a whole (it holds grid barriers); wave records
   int tail_occ = 1;                               // workgroups of pcg_tail one compute unit can hold (occupancy query at create)
+  int k4_pm = 0;                                  // MIBA_K4=pm
   int tail_split = 0;                             // 1: the PCG tail runs without grid barriers (three launches): MIBA_TAIL_SPLIT=1, or a barrier timed out once
   long long tail_timeout = 200000000ll;           // barrier patience in 100 MHz ticks (MIBA_TAIL_TIMEOUT_TICKS: tests)
   int32_t* d_tail_rec = nullptr;                  // [tail_n_vw][kTailRec] camera ranges of the tail's waves
@@ -1573,7 +1575,11 @@ int backsub_and_candidate(miba_handle h, bool reduce = true) {
         hipLaunchKernelGGL((k_mf_backsub<false, true>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));
         if (h->n_giant) hipLaunchKernelGGL((k_mf_backsub<true, true>), MIBA_BACKSUB_ARGS(h->n_giant, h->d_giant));
       } else {
-        hipLaunchKernelGGL((k_mf_backsub<false, false>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));
+        if (h->k3_cm && h->d_oxy_cm && !h->k4_pm)
+          hipLaunchKernelGGL(k_mf_backsub_cm, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_oxy, h->d_ct, h->d_cm,
+                             h->d_sc, h->d_sp, h->d_ptrec, h->d_px, h->d_yp, h->d_Xc, h->d_part_tile,
+                             CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64, nullptr}, (const double2*)h->d_oxy_cm);
+        else hipLaunchKernelGGL((k_mf_backsub<false, false>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));
         if (h->n_giant) hipLaunchKernelGGL((k_mf_backsub<true, false>), MIBA_BACKSUB_ARGS(h->n_giant, h->d_giant));
       }
 #undef MIBA_BACKSUB_ARGS
@@ -1786,6 +1792,7 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
     h->tail_occ = std::max(1, occ);
   }
   if (const char* te = getenv("MIBA_TAIL_SPLIT")) h->tail_split = te[0] == '1';
+  if (const char* te = getenv("MIBA_K4")) h->k4_pm = !strcmp(te, "pm");   // the point-major back-substitution on every tile (tests, A/B)
   if (const char* te = getenv("MIBA_TAIL_TIMEOUT_TICKS")) { const long long v = atoll(te); if (v >= 1) h->tail_timeout = v; }
   if (e != hipSuccess) {
     int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
@@ -2470,6 +2477,17 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
     UP(h->d_seg, segv.data(), segv.size());
     UP(h->d_cam_seg_off, cam_seg_off.data(), nc + 1);
     lap("device repack (oxy, camera-major copy)");
+  }
+  h->d_oxy_cm = nullptr;
+  if (h->k3_cm && !cml.src.empty()) {
+    // measurements in the order of the product's camera-major entries, for the back-substitution over the same sub-tiles
+    int32_t* d_src = nullptr;
+    const size_t ne = cml.src.size();
+    ALLOC(d_src, ne); ALLOC(h->d_oxy_cm, ne);
+    UP(d_src, cml.src.data(), ne);
+    hipLaunchKernelGGL(k_cm_gather_oxy, dim3(nblk(ne, 256)), dim3(256), 0, h->st, (int64_t)ne, (const int32_t*)d_src, (const double*)h->d_oxy, h->d_oxy_cm);
+    HIPCHK(h, hipGetLastError());
+    lap("measurements in camera-major order");
   }
 #undef ALLOC
 #undef UP

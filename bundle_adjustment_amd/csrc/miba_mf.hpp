@@ -801,28 +801,15 @@ __global__ __launch_bounds__(256) void k_mf_init(const Tile* __restrict__ tiles,
   }
 }
 
-// K4-mf: back-substitution  z_p = sp.(C^-1 (g_p - sum E_s' F_s y_c)) = zg - W sum E'u, candidate points
-// Xc = X - z, yp = z / sp, and partial[4*tile + {0,1,2}] = {sum m.(r - m/2), |X - Xc|^2, |Xc|^2}, m = u + E z.
-template <bool GIANT, bool LOSS>
-__global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
-                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
-                                                    const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
-                                                    const int32_t* __restrict__ tile_cams, const double* __restrict__ oxy,
-                                                    const double* __restrict__ ct, const double* __restrict__ cm,
-                                                    const double* __restrict__ sc, const double* __restrict__ sp,
-                                                    const double* __restrict__ ptrec, const double* __restrict__ yc,
-                                                    double* __restrict__ yp, double* __restrict__ Xc,
-                                                    double* __restrict__ partial, const double* __restrict__ omega /*LOSS*/) {
-  __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
-  __shared__ double s4[4];
-  const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
-  const Tile t = tiles[tile_id];
-  if (!GIANT && t.giant) return;
+// The point-major wavelet walk of K4 over one tile whose cameras are staged in s_cam (with y_c applied): per observation u = F y_c
+// and E'u, per point z = zg - W sum E'u, the candidate point and yp, per observation m = u + E z; adds to mcc, dp2, xp2.
+template <bool LOSS>
+__device__ __forceinline__ void mf_backsub_tile(const Tile& t, const int32_t* __restrict__ idx, const int2* __restrict__ wl,
+                                                const double* __restrict__ oxy, const double* __restrict__ sp,
+                                                const double* __restrict__ ptrec, const double* s_cam, double* __restrict__ yp,
+                                                double* __restrict__ Xc, const double* __restrict__ omega, double& mcc, double& dp2, double& xp2) {
   const int tid = threadIdx.x;
-  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0;
-  if (!GIANT) {
-    if (tid < t.ncs) mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, yc);
-    __syncthreads();
+  {
     const int lane = tid & 63, wv = tid >> 6;
     const int nwl = t.nslot / kWave;
     for (int q = wv; q < nwl; q += 4) {
@@ -875,6 +862,32 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
         }
       }
     }
+  }
+}
+
+// K4-mf: back-substitution  z_p = sp.(C^-1 (g_p - sum E_s' F_s y_c)) = zg - W sum E'u, candidate points
+// Xc = X - z, yp = z / sp, and partial[4*tile + {0,1,2}] = {sum m.(r - m/2), |X - Xc|^2, |Xc|^2}, m = u + E z.
+template <bool GIANT, bool LOSS>
+__global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
+                                                    const Group* __restrict__ grps, const int32_t* __restrict__ idx,
+                                                    const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
+                                                    const int32_t* __restrict__ tile_cams, const double* __restrict__ oxy,
+                                                    const double* __restrict__ ct, const double* __restrict__ cm,
+                                                    const double* __restrict__ sc, const double* __restrict__ sp,
+                                                    const double* __restrict__ ptrec, const double* __restrict__ yc,
+                                                    double* __restrict__ yp, double* __restrict__ Xc,
+                                                    double* __restrict__ partial, const double* __restrict__ omega /*LOSS*/) {
+  __shared__ __align__(16) double s_cam[GIANT ? 2 : kMaxCamSlots * kCamLds];
+  __shared__ double s4[4];
+  const int tile_id = GIANT ? tile_list[blockIdx.x] : blockIdx.x;
+  const Tile t = tiles[tile_id];
+  if (!GIANT && t.giant) return;
+  const int tid = threadIdx.x;
+  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0;
+  if (!GIANT) {
+    if (tid < t.ncs) mf_stage_cam(s_cam + kCamLds * tid, tile_cams[t.cam0 + tid], ct, cm, sc, yc);
+    __syncthreads();
+    mf_backsub_tile<LOSS>(t, idx, wl, oxy, sp, ptrec, s_cam, yp, Xc, omega, mcc, dp2, xp2);
   } else {
     for (int gi = 0; gi < t.ngrp; ++gi) {
       const Group G = grps[t.grp0 + gi];

@@ -290,4 +290,177 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
   }
 }
 
+// ---- K4 (back-substitution + model cost change + candidate points) over the same camera-major sub-tiles ----------------------------
+// The back-substitution is the product's first half with y_c in the cameras, then per point z = zg - W sum E'u instead of y = -W a,
+// then per observation m = u + E z and m.(r - m/2): no camera-side sums at all.  On the point-major wavelets it pays 13 ds_read_b128
+// per observation for the camera record and three lane scans (0.41 ms at Final-13682); here the record is read once per four
+// observations and the point sums are three LDS adds.  The measurements come in camera-major order (oxy_cm, gathered once per problem
+// through the layout's source slots).  Tiles with a camera in the small-angle branch or without a layout take mf_backsub_tile
+// (miba_mf.hpp) inside the same launch; giant tiles keep their own launch (k_mf_backsub<true, .>), solves with a loss the old kernel.
+
+// measurements of the camera-major entries: out[entry] = (ox, oy) of the observation in local slot src[entry]; padding entries get 0
+__global__ void k_cm_gather_oxy(int64_t n_entries, const int32_t* __restrict__ src, const double* __restrict__ oxy, double2* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  const int32_t sl = src[e];
+  double2 v = make_double2(0.0, 0.0);
+  if (sl >= 0) {
+    const int64_t chunk = sl / kChunk, l = sl % kChunk;
+    v.x = oxy[chunk * (2 * kChunk) + l];
+    v.y = oxy[chunk * (2 * kChunk) + kChunk + l];
+  }
+  out[e] = v;
+}
+
+#ifndef MIBA_K4CM_WAVES
+// Waves per SIMD the register allocation aims at.  Two: phase 1 holds the camera record (52 registers), the stash of four observations
+// (80), the points' zg and W (18) and the next sub-tile's requests; at three waves (168 registers) the compiler spills freshly loaded
+// values inside the loop, and a spill waits for every request issued before it (measured at Final-13682: 0.63 ms with three waves
+// and spills, 0.48 ms with three waves and zg / W requested after phase 1, 0.32 ms with two waves and no spill; point-major 0.42 ms).
+#define MIBA_K4CM_WAVES 2
+#endif
+__global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Tile* __restrict__ tiles, const int32_t* __restrict__ idx,
+                                                          const int2* __restrict__ wl, const double* __restrict__ oxy,
+                                                          const double* __restrict__ ct, const double* __restrict__ cm,
+                                                          const double* __restrict__ sc, const double* __restrict__ sp,
+                                                          const double* __restrict__ ptrec, const double* __restrict__ yc,
+                                                          double* __restrict__ yp, double* __restrict__ Xc, double* __restrict__ partial,
+                                                          const CmArgs A, const double2* __restrict__ oxy_cm) {
+  __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
+  __shared__ __align__(16) double s_pt[2 * kCmPtBuf];
+  __shared__ double s4[4];
+  const int ti = blockIdx.x, tid = threadIdx.x;
+  const Tile t = tiles[ti];
+  const CmTile ctile = A.tiles[ti];
+  const int4 c64 = A.cam64[(size_t)ti * kMaxCamSlots + (tid & (kMaxCamSlots - 1))];
+  if (t.giant) return;
+  bool small = false;
+  if (tid < t.ncs) {
+    mf_stage_cam(s_cam + kCamLds * tid, c64.x, ct, cm, sc, yc);
+    small = s_cam[kCamLds * tid + 24] != 0.0;
+  }
+  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0;
+  const int any_small = __syncthreads_or(small || ctile.nsub == 0);
+  if (any_small) {
+    mf_backsub_tile<false>(t, idx, wl, oxy, sp, ptrec, s_cam, yp, Xc, nullptr, mcc, dp2, xp2);
+  } else {
+    auto stage_write = [&](double* buf, const int sl, const double x0, const double x1, const double x2, const bool on) {
+      if (on) {
+        buf[sl] = x0; buf[kCmMaxPts + sl] = x1; buf[2 * kCmMaxPts + sl] = x2;
+        buf[3 * kCmMaxPts + sl] = 0.0; buf[4 * kCmMaxPts + sl] = 0.0; buf[5 * kCmMaxPts + sl] = 0.0;
+      }
+    };
+    const CmSub* subs = A.subs + ctile.sub0;
+    int my_slot = A.slot[(size_t)ctile.sub0 * kCmLanes + tid];
+    {
+      const bool on = tid < ctile.npt0;
+      const double* rp = ptrec + (size_t)kPtRec * (size_t)(ctile.pt0 + (on ? tid : 0));
+      stage_write(s_pt, my_slot, rp[0], rp[1], rp[2], on);
+    }
+    uint2 w = A.idx[(size_t)ctile.sub0 * kCmLanes + tid];
+    CmSub sb = subs[0];
+    __syncthreads();
+    for (int s = 0; s < ctile.nsub; ++s) {
+      double* buf = s_pt + (s & 1) * kCmPtBuf;
+      double* buf_next = s_pt + ((s + 1) & 1) * kCmPtBuf;
+      // requests for the next sub-tile (points, index words), this sub-tile's measurements and its points' zg, W, sp
+      const bool more = s + 1 < ctile.nsub;
+      const CmSub sn_rec = subs[more ? s + 1 : s];
+      const int n_pt0 = sb.pt0 + sb.npt, n_npt = sb.npt_next;
+      const bool on_n = more && tid < n_npt;
+      const double* rn = ptrec + (size_t)kPtRec * (size_t)(on_n ? n_pt0 + tid : sb.pt0);
+      const double nx0 = rn[0], nx1 = rn[1], nx2 = rn[2];
+      const size_t cur = (size_t)(ctile.sub0 + s) * kCmLanes + tid;
+      const size_t nxt = (size_t)(ctile.sub0 + (more ? s + 1 : s)) * kCmLanes + tid;
+      const uint2 w_next = A.idx[nxt];
+      const int slot_next = A.slot[nxt];
+      const bool on_p = tid < sb.npt;
+      const size_t pg = (size_t)(sb.pt0 + (on_p ? tid : 0));
+      const double* rw = ptrec + (size_t)kPtRec * pg + 3;
+      double Z[9];   // zg 0..2, W 3..8
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Z[k] = rw[k];
+
+      // ---- phase 1: u = F y_c, E'u into the point's sums, the residual ----
+      const unsigned e[kCmSeg] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+      const bool seg_on = (e[0] & 0x8000u) != 0;
+      const int cs = (e[0] >> 8) & 63;
+      double sE[kCmSeg][6], su0[kCmSeg], su1[kCmSeg], sr0[kCmSeg], sr1[kCmSeg];
+      if (seg_on) {
+        double cd[kCamLds];
+        mf_read_cam(cd, s_cam, cs);
+#pragma unroll
+        for (int j = 0; j < kCmSeg; ++j) {
+          double* pp = buf + (e[j] & 0xFF);
+          const double x0 = lds_read64(pp), x1 = lds_read64(pp + kCmMaxPts), x2 = lds_read64(pp + 2 * kCmMaxPts);
+          MfGeo geo;
+          mf_geom<false>(cd, x0, x1, x2, geo);
+          double u0, u1;
+          mf_forward(geo, cd, x0, x1, x2, u0, u1);
+          if (e[j] & 0x8000u) {
+            atomicAdd(pp + 3 * kCmMaxPts, geo.E[0] * u0 + geo.E[3] * u1);
+            atomicAdd(pp + 4 * kCmMaxPts, geo.E[1] * u0 + geo.E[4] * u1);
+            atomicAdd(pp + 5 * kCmMaxPts, geo.E[2] * u0 + geo.E[5] * u1);
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) sE[j][k] = geo.E[k];
+          su0[j] = u0; su1[j] = u1;
+          sr0[j] = geo.f * geo.d * geo.px;   // the projection; the measurement is subtracted in phase 2
+          sr1[j] = geo.f * geo.d * geo.py;
+        }
+      }
+      __syncthreads();
+      // ---- phase 1.5: per point z = zg - W a (left in the sums' place), candidate point, yp; the next sub-tile's points ----
+      // this lane's measurements: requested here, used in phase 2 (not in registers during phase 1)
+      double2 oo[kCmSeg];
+#pragma unroll
+      for (int j = 0; j < kCmSeg; ++j) oo[j] = oxy_cm[cur * kCmSeg + j];
+      // (the point scale is only needed for yp, which nothing in the launch waits for: requested here, used after phase 2, so
+      // that it is not in registers during phase 1)
+      const double s0 = sp[3 * pg], s1 = sp[3 * pg + 1], s2 = sp[3 * pg + 2];
+      double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+      if (on_p) {
+        double* pp = buf + my_slot;
+        const double a0 = pp[3 * kCmMaxPts], a1 = pp[4 * kCmMaxPts], a2 = pp[5 * kCmMaxPts];
+        z0 = Z[0] - (Z[3] * a0 + Z[4] * a1 + Z[6] * a2);
+        z1 = Z[1] - (Z[4] * a0 + Z[5] * a1 + Z[7] * a2);
+        z2 = Z[2] - (Z[6] * a0 + Z[7] * a1 + Z[8] * a2);
+        pp[3 * kCmMaxPts] = z0; pp[4 * kCmMaxPts] = z1; pp[5 * kCmMaxPts] = z2;
+        const double x0 = pp[0], x1 = pp[kCmMaxPts], x2 = pp[2 * kCmMaxPts];
+        const double c0 = x0 - z0, c1 = x1 - z1, c2 = x2 - z2;
+        Xc[3 * pg] = c0; Xc[3 * pg + 1] = c1; Xc[3 * pg + 2] = c2;
+        const double d0 = x0 - c0, d1 = x1 - c1, d2 = x2 - c2;   // step norm exactly as Ceres: |x - x_cand|
+        dp2 += d0 * d0 + d1 * d1 + d2 * d2;
+        xp2 += c0 * c0 + c1 * c1 + c2 * c2;
+      }
+      stage_write(buf_next, slot_next, nx0, nx1, nx2, on_n);
+      __syncthreads();
+      // ---- phase 2: m = u + E z, model cost change ----
+      if (seg_on) {
+#pragma unroll
+        for (int j = 0; j < kCmSeg; ++j) {
+          const double* pp = buf + (e[j] & 0xFF);
+          const double z0 = lds_read64(pp + 3 * kCmMaxPts), z1 = lds_read64(pp + 4 * kCmMaxPts), z2 = lds_read64(pp + 5 * kCmMaxPts);
+          const double m0 = su0[j] + sE[j][0] * z0 + sE[j][1] * z1 + sE[j][2] * z2;
+          const double m1 = su1[j] + sE[j][3] * z0 + sE[j][4] * z1 + sE[j][5] * z2;
+          if (e[j] & 0x8000u) mcc += m0 * ((sr0[j] - oo[j].x) - 0.5 * m0) + m1 * ((sr1[j] - oo[j].y) - 0.5 * m1);
+        }
+      }
+      if (on_p) { yp[3 * pg] = z0 * mf_rcp(s0); yp[3 * pg + 1] = z1 * mf_rcp(s1); yp[3 * pg + 2] = z2 * mf_rcp(s2); }
+      w = w_next;
+      my_slot = slot_next;
+      sb = sn_rec;
+    }
+  }
+  const double q0 = block_sum(mcc, s4);
+  const double q1 = block_sum(dp2, s4);
+  const double q2 = block_sum(xp2, s4);
+  if (tid == 0) {
+    partial[4 * (size_t)ti + 0] = q0;
+    partial[4 * (size_t)ti + 1] = q1;
+    partial[4 * (size_t)ti + 2] = q2;
+    partial[4 * (size_t)ti + 3] = 0.0;
+  }
+}
+
 }  // namespace miba

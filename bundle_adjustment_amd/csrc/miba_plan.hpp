@@ -682,6 +682,8 @@ struct CmLayout {
   std::vector<CmSub> subs;
   raw_vector<uint64_t> idx;                       // [subs.size()][kCmLanes]
   raw_vector<uint8_t> slot;                       // [subs.size()][kCmLanes] LDS slot of the sub-tile's k-th point
+  raw_vector<int32_t> src;                        // [subs.size()][kCmLanes][kCmSeg] local observation slot of every entry, -1: padding
+                                                  // (what the back-substitution's measurements are gathered through)
   std::vector<int32_t> rowinfo;                   // per (tile, camera slot), parallel to tile_cams: first accumulator row | rows << 8
   int64_t n_entries = 0, n_valid = 0;             // lane-steps laid out, and those that hold an observation
 };
@@ -699,7 +701,7 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
     L.rowinfo.assign(n_rows ? n_rows : 1, 0);
   }
   if (!nt) return;
-  struct Part { std::vector<CmSub> subs; std::vector<uint64_t> idx; std::vector<uint8_t> slot; std::vector<int32_t> nsub, nrows; int64_t n_valid = 0; };
+  struct Part { std::vector<CmSub> subs; std::vector<uint64_t> idx; std::vector<uint8_t> slot; std::vector<int32_t> src, nsub, nrows; int64_t n_valid = 0; };
   const unsigned nthr = std::max(1u, std::min(plan_threads((int64_t)nt, 64), (unsigned)nt));
   std::vector<Part> parts(nthr);
   plan_parallel_ranges((int64_t)nt, nthr, [&](unsigned th, int64_t ta, int64_t tb) {
@@ -743,6 +745,8 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
         const size_t base = Q.idx.size();
         Q.idx.resize(base + kCmLanes, 0);
         uint64_t* out = Q.idx.data() + base;
+        Q.src.resize((base + kCmLanes) * kCmSeg, -1);
+        int32_t* src_out = Q.src.data() + base * kCmSeg;
         auto lane_of = [](int seg) { return (seg & 3) * 64 + (seg >> 2); };
         // Position of an observation in its camera's row.  The three point-side atomic adds of a wave instruction cost
         // 8 LDS cycles times the largest number of lanes on ONE address (tools/micro/lds_atomic_bench.hip), so the
@@ -819,6 +823,7 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
               ++at_cnt[(lane >> 4) * 4 + step][best & 15];
               const uint64_t e = (uint64_t)slot | ((uint64_t)cs << 8) | 0x8000u;
               out[lane] |= e << (16 * step);
+              src_out[lane * kCmSeg + step] = pt_first_local[r] + i;
             }
           }
         }
@@ -873,6 +878,7 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
   L.subs.reserve(total_sub);
   L.idx.resize(total_sub * (size_t)kCmLanes);
   L.slot.resize(total_sub * (size_t)kCmLanes);
+  L.src.resize(total_sub * (size_t)kCmLanes * kCmSeg);
   {
     size_t ti = 0, so = 0;
     for (unsigned th = 0; th < nthr; ++th) {
@@ -885,6 +891,7 @@ inline void build_cm_layout(CmLayout& L, const std::vector<Tile>& tiles, const s
       }
       std::copy(Q.idx.begin(), Q.idx.end(), L.idx.begin() + (size_t)L.subs.size() * kCmLanes);
       std::copy(Q.slot.begin(), Q.slot.end(), L.slot.begin() + (size_t)L.subs.size() * kCmLanes);
+      std::copy(Q.src.begin(), Q.src.end(), L.src.begin() + (size_t)L.subs.size() * kCmLanes * kCmSeg);
       L.subs.insert(L.subs.end(), Q.subs.begin(), Q.subs.end());
       L.n_valid += Q.n_valid;
     }

@@ -176,3 +176,31 @@ def test_small_tiles_fall_back_by_themselves(medium, monkeypatch):
     s = solver(pr, cams0, pts0)
     assert s.kernel_times()["product_layout"] == 0
     s.close()
+
+
+@pytest.mark.parametrize("chunks", [4, 31])
+def test_backsubstitution_over_subtiles_equals_point_major(wide, monkeypatch, chunks):
+    """K4 over the camera-major sub-tiles (k_mf_backsub_cm: the default wherever the product runs camera-major) against the
+    point-major K4 of the same library (MIBA_K4=pm) on the same linear solution: point steps, model cost change and the candidate
+    state of an LM run agree to rounding (different summation orders)."""
+    pr, cams0, pts0 = wide
+    monkeypatch.setenv("MIBA_K3", "cm")
+    monkeypatch.setenv("MIBA_TILE_CHUNKS", str(chunks))
+    res = {}
+    for k4 in ("cm", "pm"):
+        monkeypatch.setenv("MIBA_K4", k4)
+        s = solver(pr, cams0, pts0)
+        assert s.kernel_times()["product_layout"] == 1
+        ls = s.linear_step(1e4, miba.default_options(linear_solver_type=miba.ITERATIVE_SCHUR, eta=1e-10, max_linear_solver_iterations=200))
+        its, summ = s.solve(miba.default_options(max_num_iterations=5, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0))
+        s.close()
+        res[k4] = (ls, its)
+    a, b = res["cm"][0], res["pm"][0]
+    assert a["n_cg"] == b["n_cg"]
+    # (the two runs' PCG solutions already differ by the product's own summation order: 1e-11 .. 1e-10 after tens of iterations)
+    assert rel(a["y_cam"], b["y_cam"]) <= 1e-9
+    assert rel(a["y_pt"], b["y_pt"]) <= 1e-9, rel(a["y_pt"], b["y_pt"])
+    assert abs(a["model_cost_change"] - b["model_cost_change"]) <= 1e-10 * abs(b["model_cost_change"])
+    ca, cb = np.array([r["cost"] for r in res["cm"][1]]), np.array([r["cost"] for r in res["pm"][1]])
+    assert len(ca) == len(cb) and np.abs(ca - cb).max() <= 1e-10 * cb[0]
+    assert [r["step_is_successful"] for r in res["cm"][1]] == [r["step_is_successful"] for r in res["pm"][1]]
