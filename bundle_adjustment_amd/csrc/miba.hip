@@ -184,6 +184,7 @@ struct miba_handle_s {
   int tail_nb = 1, tail_n_vw = 0;                 // grid of pcg_tail: resident as a whole (it holds grid barriers); wave records
   int tail_occ = 1;                               // workgroups of pcg_tail one compute unit can hold (occupancy query at create)
   int k4_pm = 0;                                  // MIBA_K4=pm
+  int xcd_remap = 1;                              // MIBA_XCD_REMAP=0: workgroups of the camera-side kernels in launch order
   int tail_split = 0;                             // 1: the PCG tail runs without grid barriers (three launches): MIBA_TAIL_SPLIT=1, or a barrier timed out once
   long long tail_timeout = 200000000ll;           // barrier patience in 100 MHz ticks (MIBA_TAIL_TIMEOUT_TICKS: tests)
   int32_t* d_tail_rec = nullptr;                  // [tail_n_vw][kTailRec] camera ranges of the tail's waves
@@ -525,12 +526,15 @@ int mf_init_launch(miba_handle h, double inv_r, const miba_options* o, bool want
   auto camrows = [&]() {
     if (!h->n_seg) return;
     Timed t(h, MIBA_K_SCHUR_INIT_CAM);
+    // XCD-aware order (see the kernel): the grid padded to a multiple of eight workgroups
+    const int remap = h->xcd_remap;
+    const int nb = remap ? (nblk(h->n_seg, 4) + 7) / 8 * 8 : nblk(h->n_seg, 4);
     if (h->loss.type != kLossNone)
-      hipLaunchKernelGGL(k_mf_camrows<true>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
-                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+      hipLaunchKernelGGL(k_mf_camrows<true>, dim3(nb), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB, remap);
     else
-      hipLaunchKernelGGL(k_mf_camrows<false>, dim3(nblk(h->n_seg, 4)), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
-                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB);
+      hipLaunchKernelGGL(k_mf_camrows<false>, dim3(nb), dim3(256), 0, h->st, h->n_seg, h->d_seg, h->d_cmo_pt, h->d_cmo_xy,
+                         h->d_ct, h->d_cm, h->d_ptrec, h->loss, h->d_slabB, remap);
   };
   if (h->n_tiles) {
     Timed t(h, MIBA_K_SCHUR_INIT);
@@ -1792,6 +1796,7 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
     h->tail_occ = std::max(1, occ);
   }
   if (const char* te = getenv("MIBA_TAIL_SPLIT")) h->tail_split = te[0] == '1';
+  if (const char* te = getenv("MIBA_XCD_REMAP")) h->xcd_remap = te[0] != '0';
   if (const char* te = getenv("MIBA_K4")) h->k4_pm = !strcmp(te, "pm");   // the point-major back-substitution on every tile (tests, A/B)
   if (const char* te = getenv("MIBA_TAIL_TIMEOUT_TICKS")) { const long long v = atoll(te); if (v >= 1) h->tail_timeout = v; }
   if (e != hipSuccess) {
@@ -2487,6 +2492,10 @@ static int set_problem_impl(miba_handle h, const miba_problem* p, std::shared_pt
     UP(d_src, cml.src.data(), ne);
     hipLaunchKernelGGL(k_cm_gather_oxy, dim3(nblk(ne, 256)), dim3(256), 0, h->st, (int64_t)ne, (const int32_t*)d_src, (const double*)h->d_oxy, h->d_oxy_cm);
     HIPCHK(h, hipGetLastError());
+    // the source slots are not needed again (4 bytes per entry)
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)d_src), h->allocs.end());
+    (void)hipFree(d_src);
     lap("measurements in camera-major order");
   }
 #undef ALLOC

@@ -553,10 +553,14 @@ __global__ __launch_bounds__(256) void k_mf_camrows(int n_seg, const int4* __res
                                                     const int32_t* __restrict__ cmo_pt, const double2* __restrict__ cmo_xy,
                                                     const double* __restrict__ ct, const double* __restrict__ cm,
                                                     const double* __restrict__ ptrec, const Loss loss,
-                                                    double* __restrict__ slab /*[n_seg][64]*/) {
+                                                    double* __restrict__ slab /*[n_seg][64]*/, const int xcd_remap) {
   __shared__ double s_red[4][64 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int sg = blockIdx.x * 4 + wv;
+  // Workgroups go to the eight XCDs in turn (blockIdx mod 8), each with an L2 of its own; the segments are in camera order and
+  // neighbouring cameras gather the same point records: XCD x takes the x-th eighth of the segments, so that those gathers meet in
+  // one L2 instead of being fetched by eight (the grid is padded to a multiple of eight workgroups; MIBA_XCD_REMAP, host side)
+  const int blk = xcd_remap ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int sg = blk * 4 + wv;
   if (sg >= n_seg) return;
   const int4 S = seg[sg];
   const int cam = __builtin_amdgcn_readfirstlane(S.x);
