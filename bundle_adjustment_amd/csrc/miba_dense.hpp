@@ -312,10 +312,12 @@ __device__ __forceinline__ void dense_block_rows(const int lane, double* sr, con
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci, first, count, cj | atomic << 30}*/,
                                                       const int32_t* __restrict__ pts, const double* __restrict__ ct,
                                                       const double* __restrict__ cm, const double* __restrict__ sc,
-                                                      const double* __restrict__ ptrec, const SDst D) {
+                                                      const double* __restrict__ ptrec, const SDst D, const int xcd_remap) {
   __shared__ double s_red[4][64 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int sg = blockIdx.x * 2 + (wv >> 1);   // two waves per segment, half of the block's rows each
+  // (XCD x takes the x-th eighth of the block-ordered segments: neighbouring blocks gather the same point records, see k_mf_camrows)
+  const int blk = xcd_remap ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int sg = blk * 2 + (wv >> 1);   // two waves per segment, half of the block's rows each
   if (sg >= n_seg) return;
   const int4 Sg = seg[sg];
   const int ci = __builtin_amdgcn_readfirstlane(Sg.x);
