@@ -184,6 +184,7 @@ struct miba_handle_s {
   int tail_nb = 1, tail_n_vw = 0;                 // grid of pcg_tail: resident as a whole (it holds grid barriers); wave records
   int tail_occ = 1;                               // workgroups of pcg_tail one compute unit can hold (occupancy query at create)
   int k4_pm = 0;                                  // MIBA_K4=pm
+  int k3_remap = 1;                               // the product's tile blocks in XCD-aware order (MIBA_XCD_REMAP=0: launch order)
   int xcd_remap = 1;                              // MIBA_XCD_REMAP=0: workgroups of the camera-side kernels in launch order
   int tail_split = 0;                             // 1: the PCG tail runs without grid barriers (three launches): MIBA_TAIL_SPLIT=1, or a barrier timed out once
   long long tail_timeout = 200000000ll;           // barrier patience in 100 MHz ticks (MIBA_TAIL_TIMEOUT_TICKS: tests)
@@ -651,9 +652,10 @@ void mf_matvec_tiles(miba_handle h, const double* x, Ctl* ctl, int pcg_iter, boo
       (const double*)h->d_omega, x, h->d_slab9, ctl
   if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_matvec<true>, MIBA_MATVEC_ARGS);
   else if (h->k3_cm)
-    hipLaunchKernelGGL(k_mf_matvec_cm, dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant,
+    hipLaunchKernelGGL(k_mf_matvec_cm, dim3((unsigned)((h->k3_remap ? (h->n_tiles + 7) / 8 * 8 : h->n_tiles) + h->n_giant)), dim3(kChunk), 0, h->st,
+                       (int)h->n_giant, h->d_tiles, h->d_giant,
                        h->d_grps, h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_slab_row, h->d_ct, h->d_cm, h->d_sc, h->d_X, h->d_ptrec, x,
-                       h->d_slab9, ctl, CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64, h->d_clk});
+                       h->d_slab9, ctl, CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64, h->d_clk}, h->k3_remap ? (int)h->n_tiles : 0);
   else hipLaunchKernelGGL(k_mf_matvec<false>, MIBA_MATVEC_ARGS);
 #undef MIBA_MATVEC_ARGS
 }
@@ -1796,7 +1798,7 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
     h->tail_occ = std::max(1, occ);
   }
   if (const char* te = getenv("MIBA_TAIL_SPLIT")) h->tail_split = te[0] == '1';
-  if (const char* te = getenv("MIBA_XCD_REMAP")) h->xcd_remap = te[0] != '0';
+  if (const char* te = getenv("MIBA_XCD_REMAP")) h->xcd_remap = h->k3_remap = te[0] != '0';
   if (const char* te = getenv("MIBA_K4")) h->k4_pm = !strcmp(te, "pm");   // the point-major back-substitution on every tile (tests, A/B)
   if (const char* te = getenv("MIBA_TAIL_TIMEOUT_TICKS")) { const long long v = atoll(te); if (v >= 1) h->tail_timeout = v; }
   if (e != hipSuccess) {
@@ -2988,13 +2990,13 @@ struct CallbackWorker {
   miba_handle h;
   miba_iteration_callback cb;
   void* user;
-  std::thread th;
   std::mutex m;
   std::condition_variable cv;
   bool has_job = false, busy = false, quit = false;
   miba_iteration job{};
   int verdict = MIBA_SOLVER_CONTINUE;
-  CallbackWorker(miba_handle h_, miba_iteration_callback cb_, void* user_) : h(h_), cb(cb_), user(user_), th([this] { run(); }) {}
+  std::thread th;   // declared last and started in the constructor's body: run() uses every member above from its first instruction
+  CallbackWorker(miba_handle h_, miba_iteration_callback cb_, void* user_) : h(h_), cb(cb_), user(user_) { th = std::thread([this] { run(); }); }
   ~CallbackWorker() {
     { std::lock_guard<std::mutex> l(m); quit = true; }
     cv.notify_all();

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
                                                          const double* __restrict__ ct, const double* __restrict__ cm,
                                                          const double* __restrict__ sc, const double* __restrict__ X,
                                                          const double* __restrict__ ptrec, const double* __restrict__ x,
-                                                         double* __restrict__ slab, const Ctl* __restrict__ ctl, const CmArgs A) {
+                                                         double* __restrict__ slab, const Ctl* __restrict__ ctl, const CmArgs A, const int n_tiles_remap) {
   // [camera records | accumulator copies (4 point-major, 2 camera-major) | rest of the point slots of the camera-major path]
   constexpr int kAccDoubles = kAccCopies * kMaxCamSlots * 9;
   constexpr int kCmAcc = kCmMaxRows * 9;
@@ -224,7 +224,14 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
   __shared__ __align__(16) double s_acc[kAccDoubles + kExtra];
   __shared__ double s4[4];
   // first trip to memory: everything that the block index alone addresses
-  const int ti = max(0, (int)blockIdx.x - n_giant);
+  // n_tiles_remap > 0: the tile blocks (padded to a multiple of eight) take the tiles so that XCD x works on the x-th eighth of them
+  // (neighbouring tiles share cameras: their tables and slab rows then meet in one L2)
+  int ti = max(0, (int)blockIdx.x - n_giant);
+  if (n_tiles_remap > 0 && (int)blockIdx.x >= n_giant) {
+    const int b = (int)blockIdx.x - n_giant, per = ((int)gridDim.x - n_giant) >> 3;
+    ti = (b & 7) * per + (b >> 3);
+    if (ti >= n_tiles_remap) return;
+  }
   const int tid = threadIdx.x;
   const int done = ctl->done;
   const Tile t = tiles[ti];
