@@ -1320,9 +1320,9 @@ int sparse_symbolic(miba_handle h) {
   const int64_t max_tiles = (int64_t)(free_all / 2 / (4096 * sizeof(double)));
 
   // Elimination order (order_tile_graph, miba_plan.hpp): the tile graph dissected into arcs that can be factored side by side, minimum
-  // degree inside.  MIBA_SPARSE_ARCS=1..4 overrides the number of arcs (tests, measurements).  Default three from 256 tile rows up: a
-  // process has four hardware queues, and with four arcs (main stream + three) two of the streams end up sharing one: Final-13682 per
-  // solve 78.5 ms with one arc, 46.9 with two, 36.5 with three, 48.0 with four.
+  // degree inside.  MIBA_SPARSE_ARCS=1..4 overrides the number of arcs (tests, measurements).  Default three from 256 tile rows up,
+  // the measured optimum: Final-13682 per solve 78.5 ms with one arc, 46.9 with two, 36.5 with three, 48.0 with four (64 with eight
+  // hardware queues instead of four: not a matter of streams sharing a queue; cause not established).
   int n_arcs = nT >= 256 ? 3 : 1;
   if (const char* ea = getenv("MIBA_SPARSE_ARCS")) { const int v = atoi(ea); if (v >= 1 && v <= 4) n_arcs = v; }
   std::vector<int32_t> pos, grp, arc_start;
