@@ -215,21 +215,21 @@ struct miba_handle_s {
   int64_t sp_n_mat = 0;            // tiles of the matrix; the right-hand-side tiles follow them
   double *d_sp_tiles = nullptr, *d_sp_Ldiag = nullptr, *d_sp_y = nullptr, *d_sp_x = nullptr;
   int32_t *d_sp_map = nullptr, *d_sp_pos = nullptr, *d_sp_grp = nullptr;
-  int32_t *d_sp_col_rows = nullptr, *d_sp_col_slots = nullptr, *d_sp_row_cols = nullptr, *d_sp_row_slots = nullptr;
-  std::vector<int64_t> sp_col_ptr, sp_row_ptr;
-  std::vector<int32_t> sp_row_last;   // column of the last tile of every tile row (-1: none)
   // dissection of the tile graph (sparse_symbolic): the columns [sp_arc[a], sp_arc[a + 1]) of arc a touch no column of another arc, so
-  // the arcs are factored side by side on sp_st[]; the separator columns [sp_arc[n_arcs], nT) follow on the main stream.  Updates of an
-  // arc that land in separator x separator tiles (or the right-hand side of a separator column) go to private tiles of the arc
-  // (d_sp_smap: [arc][(nS + 1) x nS] slots) and are added to the matrix in a fixed order once all arcs are done (k_tchol_merge).
+  // a forward step takes one column of EVERY arc (two launches for all of them); the separator columns [sp_arc[n_arcs], nT) follow one
+  // by one.  Updates of an arc that land in separator x separator tiles (or the right-hand side of a separator column) go to private
+  // tiles of the arc and are added to the matrix in a fixed order once all arcs are done (k_tchol_merge).  The workgroup lists of
+  // all launches (d_sp_wg) are written once, here: sp_fwd / sp_bwd hold every step's offsets into them.
+  struct SpStep { int64_t col0; int32_t n_col; int64_t upd0; int32_t n_upd; };
   int sp_n_arcs = 1;
   std::vector<int32_t> sp_arc;
-  int32_t *d_sp_smap = nullptr, *d_sp_merge_ptr = nullptr, *d_sp_merge_src = nullptr, *d_sp_merge_dst = nullptr;
+  int4* d_sp_wg = nullptr;
+  std::vector<SpStep> sp_fwd, sp_bwd;   // backward steps use col0 / n_col only
+  size_t sp_merge_at = 0;               // forward steps before the merge of the private tiles
+  int32_t *d_sp_merge_ptr = nullptr, *d_sp_merge_src = nullptr, *d_sp_merge_dst = nullptr;
   int64_t sp_n_priv = 0;           // private tiles (behind the right-hand-side tiles)
   int32_t sp_n_merge = 0;          // destination tiles with private contributions
   int64_t sp_fill_tiles = 0;       // tiles below the diagonal after fill (reported)
-  hipStream_t sp_st[3] = {nullptr, nullptr, nullptr};   // the extra streams of the arcs
-  hipEvent_t sp_ev_fork = nullptr, sp_ev_join[3] = {nullptr, nullptr, nullptr};
   double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
   double *d_sum = nullptr, *d_max = nullptr;   // [S_COUNT] each
   Ctl* d_ctl = nullptr;
@@ -1319,16 +1319,58 @@ int sparse_symbolic(miba_handle h) {
 
   const int64_t max_tiles = (int64_t)(free_all / 2 / (4096 * sizeof(double)));
 
-  // Elimination order (order_tile_graph, miba_plan.hpp): the tile graph dissected into arcs that can be factored side by side, minimum
-  // degree inside.  MIBA_SPARSE_ARCS=1..4 overrides the number of arcs (tests, measurements).  Default three from 256 tile rows up,
-  // the measured optimum: Final-13682 per solve 78.5 ms with one arc, 46.9 with two, 36.5 with three, 48.0 with four (64 with eight
-  // hardware queues instead of four: not a matter of streams sharing a queue; cause not established).
-  int n_arcs = nT >= 256 ? 3 : 1;
-  if (const char* ea = getenv("MIBA_SPARSE_ARCS")) { const int v = atoi(ea); if (v >= 1 && v <= 4) n_arcs = v; }
+  // Elimination order (order_tile_graph, miba_plan.hpp): the tile graph dissected into arcs whose columns are factored side by side,
+  // minimum degree inside.  The factorisation is a chain of steps, each two launches whose latency (about 29 us together) the
+  // work of a narrow column does not fill: the number of arcs trades the length of the arcs' chains (tile rows / arcs) against that
+  // of the separator's (about 8 tile rows per cut at Final-13682) and its denser columns.  The symbolic phase orders the graph for a
+  // few arc counts and keeps the cheapest under tile_order_cost's model (every rank sees the same graph and takes the same
+  // decision); MIBA_SPARSE_ARCS=1..64 fixes the number instead (tests, measurements).
+  int n_arcs = 1;
   std::vector<int32_t> pos, grp, arc_start;
   std::vector<std::vector<int32_t>> col_nodes;
   int64_t n_off = 0;
-  if (!order_tile_graph(adj, nT, n_arcs, max_tiles, h->cfg.log_level, n_arcs, grp, pos, col_nodes, arc_start, n_off)) return MIBA_OK;   // does not fit: sparse_state stays -1
+  {
+    std::vector<int> cand;
+    if (const char* ea = getenv("MIBA_SPARSE_ARCS")) { const int v = atoi(ea); if (v >= 1 && v <= kMaxArcs) cand.push_back(v); }
+    if (cand.empty()) {
+      for (int v : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64})
+        if (v == 1 || nT >= 32 * v) cand.push_back(v);
+    }
+    // (the candidates are ordered side by side on host threads: at 7,143 tile rows one ordering takes 40 ms)
+    struct Cand { std::vector<uint64_t> adj; std::vector<int32_t> pos, grp, arc; std::vector<std::vector<int32_t>> nodes; int64_t off = 0; int got = 0; bool ok = false; double cost = 0.0; };
+    std::vector<Cand> cs(cand.size());
+    for (size_t i = 0; i < cand.size(); ++i) {
+      if (i + 1 == cand.size()) cs[i].adj = std::move(adj);
+      else cs[i].adj = adj;
+    }
+    auto order_one = [&](size_t i) {
+      Cand& c = cs[i];
+      c.got = cand[i];
+      c.ok = order_tile_graph(c.adj, nT, cand[i], max_tiles, h->cfg.log_level, c.got, c.grp, c.pos, c.nodes, c.arc, c.off);
+      if (c.ok) c.cost = tile_order_cost(c.nodes, c.arc, c.got, nT);
+    };
+    {
+      std::vector<std::thread> th;
+      for (size_t i = 1; i < cand.size(); ++i) th.emplace_back(order_one, i);
+      order_one(0);
+      for (auto& t : th) t.join();
+    }
+    double best = 0.0;
+    bool have = false;
+    for (size_t i = 0; i < cand.size(); ++i) {
+      Cand& c = cs[i];
+      if (!c.ok) continue;
+      if (c.got != cand[i] && cand[i] != 1 && cand.size() > 1) continue;   // not dissected that finely: the plain order is a candidate of its own
+      if (h->cfg.log_level > 0 || getenv("MIBA_SPARSE_DEBUG"))
+        fprintf(stderr, "[miba] tile order with %d arc(s): %lld tiles below the diagonal, %d separator rows, modelled %.2f ms\n", c.got, (long long)c.off,
+                nT - c.arc[c.got], c.cost * 1e-3);
+      if (!have || c.cost < best) {
+        have = true; best = c.cost; n_arcs = c.got; n_off = c.off;
+        pos.swap(c.pos); grp.swap(c.grp); arc_start.swap(c.arc); col_nodes.swap(c.nodes);
+      }
+    }
+    if (!have) return MIBA_OK;   // does not fit: sparse_state stays -1
+  }
   const int sep0 = arc_start[n_arcs];          // first separator column (nT: none)
   const int nS = nT - sep0;
 
@@ -1391,21 +1433,102 @@ int sparse_symbolic(miba_handle h) {
     }
     merge_ptr.push_back((int32_t)contrib.size());
   }
-  std::vector<int32_t> row_cols, row_slots;
-  std::vector<int64_t> row_ptr(nT + 1, 0);
-  std::vector<int32_t> row_last(nT, -1);
-  for (int r = 0; r < nT; ++r) {
-    row_ptr[r] = (int64_t)row_cols.size();
-    for (auto& e : row_list[r]) { row_cols.push_back(e.first); row_slots.push_back(e.second); }
-    row_last[r] = row_list[r].empty() ? -1 : row_list[r].back().first;
+  // The workgroup lists of every launch.  Forward: step s of the arcs' phase takes column arc_start[a] + s of every arc a that has one,
+  // then every separator column is a step of its own (one arc: every column).  Backward: the separator rows one by one from the last,
+  // then row arc_start[a + 1] - 1 - s of every arc (below the separator the rows of an arc touch only columns of the arc).
+  const bool split = n_arcs > 1;
+  std::vector<miba_handle_s::SpStep> fwd, bwd;
+  std::vector<std::vector<int32_t>> fwd_cols, bwd_rows;
+  size_t merge_at = 0;
+  {
+    int longest = 0;
+    for (int a = 0; a < n_arcs && split; ++a) longest = std::max(longest, (int)(arc_start[a + 1] - arc_start[a]));
+    for (int st = 0; st < longest; ++st) {
+      std::vector<int32_t> ks;
+      for (int a = 0; a < n_arcs; ++a)
+        if (arc_start[a] + st < arc_start[a + 1]) ks.push_back(arc_start[a] + st);
+      fwd_cols.push_back(ks);
+    }
+    merge_at = fwd_cols.size();
+    for (int k = split ? sep0 : 0; k < nT; ++k) fwd_cols.push_back({k});
+    for (int k = nT - 1; k >= (split ? sep0 : 0); --k) bwd_rows.push_back({k});
+    for (int st = 0; st < longest; ++st) {
+      std::vector<int32_t> ks;
+      for (int a = 0; a < n_arcs; ++a)
+        if (arc_start[a + 1] - 1 - st >= arc_start[a]) ks.push_back(arc_start[a + 1] - 1 - st);
+      bwd_rows.push_back(ks);
+    }
   }
-  row_ptr[nT] = (int64_t)row_cols.size();
+  auto chain_start = [&](int k) {   // first row of the chain of backward steps row k belongs to
+    if (!split || k >= sep0) return split ? sep0 : 0;
+    int a = 0;
+    while (k >= arc_start[a + 1]) ++a;
+    return (int)arc_start[a];
+  };
+  int64_t n_wg = 0;
+  for (auto& ks : fwd_cols)
+    for (int32_t k : ks) {
+      const int64_t m = col_ptr[k + 1] - col_ptr[k] - 1;
+      n_wg += m + m * (m - 1) / 2;   // (the right-hand-side row is never a column: m - 1 columns, pairs I >= J)
+    }
+  n_wg += n_off + nT;
+  if ((double)n_wg * sizeof(int4) > free_all / 8) return MIBA_OK;   // the lists do not fit
+  std::vector<int4> wg;
+  wg.reserve((size_t)n_wg);
+  for (auto& ks : fwd_cols) {
+    miba_handle_s::SpStep S{(int64_t)wg.size(), 0, 0, 0};
+    for (int32_t k : ks) {
+      const int64_t c0 = col_ptr[k];
+      const int m = (int)(col_ptr[k + 1] - c0) - 1;   // tiles below the diagonal, the right-hand-side tile among them
+      for (int b = 0; b < m; ++b) wg.push_back(int4{k, col_slots[c0 + 1 + b], k, b});
+    }
+    S.n_col = (int32_t)(wg.size() - S.col0);
+    S.upd0 = (int64_t)wg.size();
+    for (int32_t k : ks) {
+      const int64_t c0 = col_ptr[k];
+      const int m = (int)(col_ptr[k + 1] - c0) - 1;
+      const int32_t* rows = col_rows.data() + c0 + 1;
+      const int32_t* slots = col_slots.data() + c0 + 1;
+      const int32_t* sm = nullptr;
+      if (split && k < sep0) {
+        int a = 0;
+        while (k >= arc_start[a + 1]) ++a;
+        sm = smap.data() + (size_t)a * (nS + 1) * nS;
+      }
+      for (int J = 0; J < m; ++J) {
+        if (rows[J] >= nT) break;
+        for (int I = J; I < m; ++I) {
+          const int32_t d = (sm && rows[J] >= sep0) ? sm[(size_t)(rows[I] - sep0) * nS + (rows[J] - sep0)] : map[(size_t)rows[I] * nT + rows[J]];
+          if (d < 0) return fail(h, MIBA_ERR_INVALID, "tile (%d, %d) is missing from the fill of column %d", rows[I], rows[J], k);
+          wg.push_back(int4{slots[I], slots[J], d, 0});
+        }
+      }
+    }
+    S.n_upd = (int32_t)(wg.size() - S.upd0);
+    fwd.push_back(S);
+  }
+  {
+    std::vector<int32_t> lead_into(nT + 1, 0);   // row k: x_k was formed by the step of row k + 1
+    for (auto& ks : bwd_rows) {
+      miba_handle_s::SpStep S{(int64_t)wg.size(), 0, 0, 0};
+      for (int32_t k : ks) {
+        const auto& L = row_list[k];   // (column, slot), columns ascending
+        const int have_x = lead_into[k] ? 1 : 0;
+        const bool ahead = !L.empty() && L.back().first == k - 1 && k - 1 >= chain_start(k);
+        if (L.empty()) wg.push_back(int4{k, -1, 0, have_x | 4});
+        for (size_t i = 0; i < L.size(); ++i)
+          wg.push_back(int4{k, L[i].second, L[i].first, have_x | ((ahead && i + 1 == L.size()) ? 2 : 0) | (i == 0 ? 4 : 0)});
+        if (ahead) lead_into[k - 1] = 1;
+      }
+      S.n_col = (int32_t)(wg.size() - S.col0);
+      bwd.push_back(S);
+    }
+  }
 
   int rc;
 #define SP_ALLOC(ptr, n) if ((rc = dev_alloc(h, &ptr, (size_t)(n)))) return rc
   SP_ALLOC(h->d_sp_tiles, (size_t)(n_mat + nT + n_priv) * 4096);
-  if (n_arcs > 1) {
-    SP_ALLOC(h->d_sp_smap, smap.size());
+  if (split) {
     SP_ALLOC(h->d_sp_merge_ptr, merge_ptr.size());
     SP_ALLOC(h->d_sp_merge_src, merge_src.size() ? merge_src.size() : 1);
     SP_ALLOC(h->d_sp_merge_dst, merge_dst.size() ? merge_dst.size() : 1);
@@ -1416,22 +1539,16 @@ int sparse_symbolic(miba_handle h) {
   SP_ALLOC(h->d_sp_map, map.size());
   SP_ALLOC(h->d_sp_pos, nT);
   SP_ALLOC(h->d_sp_grp, nT);
-  SP_ALLOC(h->d_sp_col_rows, col_rows.size());
-  SP_ALLOC(h->d_sp_col_slots, col_slots.size());
-  SP_ALLOC(h->d_sp_row_cols, row_cols.size());
-  SP_ALLOC(h->d_sp_row_slots, row_slots.size());
+  SP_ALLOC(h->d_sp_wg, wg.size());
 #undef SP_ALLOC
   if (!h->d_dflag && (rc = dev_alloc(h, &h->d_dflag, 1))) return rc;
   if ((rc = upload(h, h->d_sp_map, map.data(), map.size()))) return rc;
   if ((rc = upload(h, h->d_sp_pos, pos.data(), (size_t)nT))) return rc;
   if ((rc = upload(h, h->d_sp_grp, grp.data(), (size_t)nT))) return rc;
-  if ((rc = upload(h, h->d_sp_col_rows, col_rows.data(), col_rows.size()))) return rc;
-  if ((rc = upload(h, h->d_sp_col_slots, col_slots.data(), col_slots.size()))) return rc;
-  if ((rc = upload(h, h->d_sp_row_cols, row_cols.data(), row_cols.size()))) return rc;
-  if ((rc = upload(h, h->d_sp_row_slots, row_slots.data(), row_slots.size()))) return rc;
-  h->sp_col_ptr.swap(col_ptr);
-  h->sp_row_ptr.swap(row_ptr);
-  h->sp_row_last.swap(row_last);
+  if ((rc = upload(h, h->d_sp_wg, wg.data(), wg.size()))) return rc;
+  h->sp_fwd.swap(fwd);
+  h->sp_bwd.swap(bwd);
+  h->sp_merge_at = merge_at;
   h->sp_nT = nT;
   h->sp_n_mat = n_mat;
   h->sp_n_arcs = n_arcs;
@@ -1439,16 +1556,10 @@ int sparse_symbolic(miba_handle h) {
   h->sp_n_priv = n_priv;
   h->sp_n_merge = (int32_t)merge_dst.size();
   h->sp_fill_tiles = n_off;
-  if (n_arcs > 1) {
-    if ((rc = upload(h, h->d_sp_smap, smap.data(), smap.size()))) return rc;
+  if (split) {
     if ((rc = upload(h, h->d_sp_merge_ptr, merge_ptr.data(), merge_ptr.size()))) return rc;
     if (!merge_src.empty() && (rc = upload(h, h->d_sp_merge_src, merge_src.data(), merge_src.size()))) return rc;
     if (!merge_dst.empty() && (rc = upload(h, h->d_sp_merge_dst, merge_dst.data(), merge_dst.size()))) return rc;
-    for (int q = 0; q < 3; ++q) {
-      if (!h->sp_st[q]) HIPCHK(h, hipStreamCreateWithFlags(&h->sp_st[q], hipStreamNonBlocking));
-      if (!h->sp_ev_join[q]) HIPCHK(h, hipEventCreateWithFlags(&h->sp_ev_join[q], hipEventDisableTiming));
-    }
-    if (!h->sp_ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->sp_ev_fork, hipEventDisableTiming));
   }
   if (h->cfg.log_level > 0 || getenv("MIBA_SPARSE_DEBUG"))
     fprintf(stderr, "[miba] tile factorisation: %d tile rows, %lld tiles below the diagonal after fill, %d arc(s), %d separator rows, %lld private tiles\n",
@@ -1470,75 +1581,20 @@ int sparse_solve(miba_handle h, int* status) {
   hipLaunchKernelGGL(k_tchol_pad, dim3(nb64), dim3(256), 0, h->st, h->n_cam, nT, T, (const int32_t*)h->d_sp_grp);
   hipLaunchKernelGGL(k_tchol_rhs, dim3(nb64), dim3(256), 0, h->st, h->n_cam, nT, (const double*)h->d_rhs, T, (int)n_mat, (const int32_t*)h->d_sp_grp);
   HIPCHK(h, hipMemsetAsync(h->d_dflag, 0, sizeof(int32_t), h->st));
-  const int n_arcs = h->sp_n_arcs;
-  const int sep0 = h->sp_arc[n_arcs];
-  // the two launches of column step k on stream st; an arc's column sends its separator updates to the arc's private tiles
-  auto column = [&](int k, hipStream_t st, const int32_t* smap) {
-    const int64_t c0 = h->sp_col_ptr[k];
-    const int cnt = (int)(h->sp_col_ptr[k + 1] - c0);   // diagonal, tiles below it, right-hand side
-    double* W = h->d_sp_Ldiag + (size_t)k * 4096;
-    const int m = cnt - 1;   // tiles below the diagonal, the right-hand-side tile among them
-    hipLaunchKernelGGL(k_tchol_col, dim3(m), dim3(256), 0, st, T, (const int32_t*)(h->d_sp_col_slots + c0), W, (int*)h->d_dflag);
-    if (m > 1)
-      hipLaunchKernelGGL(k_tchol_update, dim3(m, m), dim3(256), 0, st, T, (const int32_t*)(h->d_sp_col_rows + c0 + 1),
-                         (const int32_t*)(h->d_sp_col_slots + c0 + 1), (const int32_t*)h->d_sp_map, nT, smap, sep0);
-  };
-  // backward step of tile row k on stream st
-  auto backward = [&](int k, hipStream_t st, int& have_x) {
-    const int64_t r0 = h->sp_row_ptr[k];
-    const int nr = (int)(h->sp_row_ptr[k + 1] - r0);
-    // the tiles of a row are listed by ascending column: the last one is (k, k - 1) if that tile exists
-    const int ahead = (nr > 0 && h->sp_row_last[k] == k - 1) ? nr - 1 : -1;
-    hipLaunchKernelGGL(k_tchol_bwd, dim3(nr > 0 ? nr : 1), dim3(kNB), 0, st, (const double*)T, k, nr, (const int32_t*)(h->d_sp_row_cols + r0),
-                       (const int32_t*)(h->d_sp_row_slots + r0), (const double*)h->d_sp_Ldiag, h->d_sp_y, h->d_sp_x, have_x, ahead);
-    have_x = ahead >= 0;
-  };
-  // arc a runs on the main stream (a = 0) or on one of the extra streams; fork / join by events
-  auto arc_stream = [&](int a) { return a == 0 ? h->st : h->sp_st[(a - 1) % 3]; };
-  auto fork = [&]() -> int {
-    HIPCHK(h, hipEventRecord(h->sp_ev_fork, h->st));
-    for (int q = 0; q < 3 && q < n_arcs - 1; ++q) HIPCHK(h, hipStreamWaitEvent(h->sp_st[q], h->sp_ev_fork, 0));
-    return MIBA_OK;
-  };
-  auto join = [&]() -> int {
-    for (int q = 0; q < 3 && q < n_arcs - 1; ++q) {
-      HIPCHK(h, hipEventRecord(h->sp_ev_join[q], h->sp_st[q]));
-      HIPCHK(h, hipStreamWaitEvent(h->st, h->sp_ev_join[q], 0));
-    }
-    return MIBA_OK;
-  };
-  if (n_arcs > 1) {
-    if (h->sp_n_priv) HIPCHK(h, hipMemsetAsync(T + (size_t)(n_mat + nT) * 4096, 0, (size_t)h->sp_n_priv * 4096 * sizeof(double), h->st));
-    if ((rc = fork())) return rc;
-    const size_t smap_stride = (size_t)(nT - sep0 + 1) * (nT - sep0);
-    // (round-robin over the arcs' columns, so that the launches of all streams are enqueued side by side)
-    std::vector<int> at(h->sp_arc.begin(), h->sp_arc.begin() + n_arcs);
-    for (bool any = true; any;) {
-      any = false;
-      for (int a = 0; a < n_arcs; ++a)
-        if (at[a] < h->sp_arc[a + 1]) { column(at[a]++, arc_stream(a), h->d_sp_smap + a * smap_stride); any = true; }
-    }
-    if ((rc = join())) return rc;
-    if (h->sp_n_merge)
+  // one stream, one chain of launches: a forward step is the column launch and the update launch of all its columns
+  if (h->sp_n_priv) HIPCHK(h, hipMemsetAsync(T + (size_t)(n_mat + nT) * 4096, 0, (size_t)h->sp_n_priv * 4096 * sizeof(double), h->st));
+  for (size_t i = 0; i < h->sp_fwd.size(); ++i) {
+    if (i == h->sp_merge_at && h->sp_n_merge)
       hipLaunchKernelGGL(k_tchol_merge, dim3(h->sp_n_merge), dim3(256), 0, h->st, T, (const int32_t*)h->d_sp_merge_ptr, (const int32_t*)h->d_sp_merge_src,
                          (const int32_t*)h->d_sp_merge_dst);
+    const miba_handle_s::SpStep& S = h->sp_fwd[i];
+    hipLaunchKernelGGL(k_tchol_col, dim3(S.n_col), dim3(256), 0, h->st, T, (const int4*)(h->d_sp_wg + S.col0), h->d_sp_Ldiag, (int*)h->d_dflag);
+    if (S.n_upd) hipLaunchKernelGGL(k_tchol_update, dim3(S.n_upd), dim3(256), 0, h->st, T, (const int4*)(h->d_sp_wg + S.upd0));
   }
-  for (int k = (n_arcs > 1 ? sep0 : 0); k < nT; ++k) column(k, h->st, nullptr);
   hipLaunchKernelGGL(k_tchol_gety, dim3(nb64), dim3(256), 0, h->st, nT, (const double*)T, (int)n_mat, h->d_sp_y);
-  int have_x = 0;
-  for (int k = nT - 1; k >= (n_arcs > 1 ? sep0 : 0); --k) backward(k, h->st, have_x);
-  if (n_arcs > 1) {
-    // below the separator the rows of an arc touch only columns of the arc
-    if ((rc = fork())) return rc;
-    std::vector<int> at(n_arcs), hx(n_arcs, 0);
-    for (int a = 0; a < n_arcs; ++a) at[a] = h->sp_arc[a + 1] - 1;
-    for (bool any = true; any;) {
-      any = false;
-      for (int a = 0; a < n_arcs; ++a)
-        if (at[a] >= h->sp_arc[a]) { backward(at[a]--, arc_stream(a), hx[a]); any = true; }
-    }
-    if ((rc = join())) return rc;
-  }
+  for (const miba_handle_s::SpStep& S : h->sp_bwd)
+    hipLaunchKernelGGL(k_tchol_bwd, dim3(S.n_col), dim3(kNB), 0, h->st, (const double*)T, (const int4*)(h->d_sp_wg + S.col0), (const double*)h->d_sp_Ldiag,
+                       h->d_sp_y, h->d_sp_x);
   hipLaunchKernelGGL(k_tchol_unperm, dim3(nblk(9 * (size_t)h->n_cam, 256)), dim3(256), 0, h->st, h->n_cam, (const double*)h->d_sp_x,
                      (const int32_t*)h->d_sp_pos, h->d_px);
   HIPCHK(h, hipGetLastError());
@@ -1984,11 +2040,6 @@ int miba_destroy(miba_handle h) {
   }
   if (h->ev_state) (void)hipEventDestroy(h->ev_state);
   if (h->st2) { (void)hipStreamSynchronize(h->st2); (void)hipStreamDestroy(h->st2); }
-  for (int q = 0; q < 3; ++q) {
-    if (h->sp_st[q]) { (void)hipStreamSynchronize(h->sp_st[q]); (void)hipStreamDestroy(h->sp_st[q]); }
-    if (h->sp_ev_join[q]) (void)hipEventDestroy(h->sp_ev_join[q]);
-  }
-  if (h->sp_ev_fork) (void)hipEventDestroy(h->sp_ev_fork);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   if (h->st) (void)hipStreamDestroy(h->st);
@@ -2039,8 +2090,8 @@ int miba_plan_product_stats(const miba_problem* p, double* out10) {
 }
 
 int miba_plan_tile_order(int32_t n_rows, const int32_t* eu, const int32_t* ev, int64_t n_edges, int32_t n_arcs, int32_t* pos_out,
-                         int32_t* arc_start_out, int32_t* n_arcs_out, int64_t* fill_tiles) {
-  if (n_rows < 1 || n_rows > 32768 || n_edges < 0 || (n_edges && (!eu || !ev)) || !pos_out || !arc_start_out || n_arcs < 1 || n_arcs > 4)
+                         int32_t* arc_start_out, int32_t* n_arcs_out, int64_t* fill_tiles, double* cost_us) {
+  if (n_rows < 1 || n_rows > 32768 || n_edges < 0 || (n_edges && (!eu || !ev)) || !pos_out || !arc_start_out || n_arcs < 1 || n_arcs > kMaxArcs)
     return fail(nullptr, MIBA_ERR_INVALID, "bad tile graph");
   const size_t nW = ((size_t)n_rows + 63) / 64;
   std::vector<uint64_t> adj((size_t)n_rows * nW, 0);
@@ -2058,9 +2109,10 @@ int miba_plan_tile_order(int32_t n_rows, const int32_t* eu, const int32_t* ev, i
   if (!order_tile_graph(adj, n_rows, n_arcs, (int64_t)1 << 40, 0, na, grp, pos, col_nodes, arc_start, n_off))
     return fail(nullptr, MIBA_ERR_LIMIT, "tile graph too large");
   for (int32_t v = 0; v < n_rows; ++v) pos_out[v] = pos[v];
-  for (int a = 0; a < 5; ++a) arc_start_out[a] = arc_start[std::min(a, na)];
+  for (int a = 0; a <= n_arcs; ++a) arc_start_out[a] = arc_start[std::min(a, na)];
   if (n_arcs_out) *n_arcs_out = na;
   if (fill_tiles) *fill_tiles = n_off;
+  if (cost_us) *cost_us = tile_order_cost(col_nodes, arc_start, na, n_rows);
   return MIBA_OK;
 }
 

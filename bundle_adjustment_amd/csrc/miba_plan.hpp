@@ -560,6 +560,7 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
 // Out: the order (grp[k] = tile row eliminated at step k, pos = its inverse), per step the rows below the diagonal after fill
 // (col_nodes, as tile rows), their total n_off, the number of arcs the order was dissected into and the first step of every arc
 // (arc_start[n_arcs] = first separator step, nT when there is none).  false: more than max_tiles tiles.
+constexpr int kMaxArcs = 64;   // arcs of the dissected order (part[] below is int8_t)
 inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int n_arcs_wanted, const int64_t max_tiles, const int log_level,
                              int& n_arcs_out, std::vector<int32_t>& grp_out, std::vector<int32_t>& pos_out,
                              std::vector<std::vector<int32_t>>& col_nodes_out, std::vector<int32_t>& arc_start_out, int64_t& n_off_out) {
@@ -571,7 +572,7 @@ inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int
   // first rows behind every cut, on a ring also the last rows, which close it).  Interiors of different arcs then share no edge, and
   // eliminating an interior row creates fill only inside its arc and towards the separator: the arcs' columns are independent of
   // each other, the separator rows come last.  Only camera numberings with locality (what BAL files and the stand-in have) dissect
-  // this way; if the separator takes more than a third of the rows the order stays plain minimum degree on one stream.
+  // this way; if the separator takes more than a third of the rows the order stays plain minimum degree, one chain.
   if (nT < 8 * n_arcs) n_arcs = 1;
   std::vector<int8_t> part(nT, 0);   // arc of a tile row; n_arcs = separator
   if (n_arcs > 1) {
@@ -651,6 +652,32 @@ inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int
   arc_start_out.swap(arc_start);
   n_off_out = n_off;
   return true;
+}
+
+
+// What the numeric phase pays for an order, in microseconds (sparse_symbolic chooses the number of arcs by it).  A forward step is two
+// dependent launches, column and update, for one column of every arc (a separator column alone): about 29 us of launch and memory
+// latency however little work they hold (measured at Final-13682, whose columns hold a dozen tiles), and past that the update's tile
+// products at what the chip sustains on them (64^3 fp64 multiply-adds each, about 20 TFLOP/s: 0.026 us); a backward step is one
+// launch, about 6 us.
+inline double tile_order_cost(const std::vector<std::vector<int32_t>>& col_nodes, const std::vector<int32_t>& arc_start, const int n_arcs, const int nT) {
+  auto pairs = [&](int k) { const double m = (double)col_nodes[k].size() + 1.0; return 0.5 * m * (m + 1.0); };
+  const double t_step = 29.0, t_pair = 0.026, t_back = 6.0;
+  double us = 0.0;
+  int sep0 = 0;
+  if (n_arcs > 1) {
+    sep0 = arc_start[n_arcs];
+    int longest = 0;
+    for (int a = 0; a < n_arcs; ++a) longest = std::max(longest, (int)(arc_start[a + 1] - arc_start[a]));
+    for (int st = 0; st < longest; ++st) {
+      double w = 0.0;
+      for (int a = 0; a < n_arcs; ++a)
+        if (arc_start[a] + st < arc_start[a + 1]) w += pairs(arc_start[a] + st);
+      us += std::max(t_step, t_pair * w) + t_back;
+    }
+  }
+  for (int k = sep0; k < nT; ++k) us += std::max(t_step, t_pair * pairs(k)) + t_back;
+  return us;
 }
 
 

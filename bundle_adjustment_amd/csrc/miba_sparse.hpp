@@ -126,15 +126,17 @@ __device__ __forceinline__ bool tchol_diag_wave(const double* __restrict__ A, co
   return bad;   // (M is lower block triangular: the blocks of As above the diagonal still hold what is left of the tile)
 }
 
-// Column step k, first launch: workgroup b turns tile b of the column (slots[1 + b]: the tiles below the diagonal, the
-// right-hand-side tile last) into X = A W = A L^-T.  Every workgroup factors and inverts the diagonal tile (slots[0]) itself,
+// Column step, first launch.  A launch takes one column of EVERY arc of the dissected order at once (the arcs' columns do not touch
+// each other: sparse_symbolic in miba.hip), a separator column alone: workgroup e = wg[blockIdx.x] = {slot of the column's diagonal tile,
+// slot of its own tile (one of the tiles below the diagonal, the right-hand-side tile among them), column k, index b of the tile in
+// the column} turns its tile into X = A W = A L^-T.  Every workgroup factors and inverts the diagonal tile itself,
 // on its first wave, while the loads of its own tile are in flight: a launch that does it once and hands W over through memory
-// costs the column another launch ramp and two trips to memory (9 us where the product itself is 1.5).  Workgroup 0 leaves W
-// for the backward substitution.  Product on the fp64 matrix cores: wave = 16 rows, A fragment lane l = A[l & 15][4 kk + (l >> 4)],
+// costs the column another launch ramp and two trips to memory (9 us where the product itself is 1.5).  The column's workgroup 0 leaves
+// W for the backward substitution.  Product on the fp64 matrix cores: wave = 16 rows, A fragment lane l = A[l & 15][4 kk + (l >> 4)],
 // B[k][n] = W[k][16 nt + n] = M[16 nt + n][k] (zero for k >= 16 (nt + 1): M is lower block triangular), D: row (l >> 4) + 4 reg,
 // column l & 15.  In place: a wave reads all of its sixteen rows before it writes any of them, and nobody else touches them.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_col(double* __restrict__ tiles, const int32_t* __restrict__ slots /*of this column*/,
-                                                   double* __restrict__ Winv /*[64 * 64]*/, int* __restrict__ flag) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_col(double* __restrict__ tiles, const int4* __restrict__ wg /*of this step*/,
+                                                   double* __restrict__ Winv_all /*[column][64 * 64]*/, int* __restrict__ flag) {
   __shared__ __align__(16) double As[kNB * kLs];
   __shared__ __align__(16) double Lt[kNB * kLs];
   __shared__ double Lr[kNB];
@@ -142,14 +144,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tid = threadIdx.x;
   const int l = tid & 63, wv = tid >> 6;
   const int ar = l & 15, ak = l >> 4;
-  double* A = tiles + (size_t)slots[1 + blockIdx.x] * 4096;
+  const int4 e = wg[blockIdx.x];
+  double* A = tiles + (size_t)e.y * 4096;
   double af[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
   if (wv == 0) {
-    const bool bad = tchol_diag_wave(tiles + (size_t)slots[0] * 4096, l, As, Lt, Lr, Sb);
-    if (blockIdx.x == 0) {
+    const bool bad = tchol_diag_wave(tiles + (size_t)e.x * 4096, l, As, Lt, Lr, Sb);
+    if (e.w == 0) {
       if (bad && l == 0) *flag = 1;
+      double* Winv = Winv_all + (size_t)e.z * 4096;
 #pragma unroll 16
       for (int c = 0; c < kNB; ++c) Winv[c * kNB + l] = (ak <= (c >> 4)) ? As[c * kLs + l] : 0.0;
     }
@@ -168,24 +172,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int reg = 0; reg < 4; ++reg) A[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] = c[nt][reg];
 }
 
-// Column step k, second launch, trailing update: tile (r_I, r_J) -= L(r_I, k) L(r_J, k)' for the tiles I >= J below the diagonal of the
-// column (rows[] / slots[] list them, diagonal excluded); the destination comes from the tile map (symbolic fill guarantees it).
-// A column of an arc (smap != null; the arcs of the dissected order run side by side on several streams) sends the updates whose
-// column lies in the separator (rJ >= sep0) to the arc's private tiles instead: smap[(rI - sep0) * (nT - sep0) + (rJ - sep0)],
-// zero before the factorisation and added to the matrix by k_tchol_merge once all arcs are done.
-__global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles, const int32_t* __restrict__ rows,
-                                                      const int32_t* __restrict__ slots, const int32_t* __restrict__ map, int nT,
-                                                      const int32_t* __restrict__ smap, int sep0) {
+// Column step, second launch, trailing update: tile (r_I, r_J) -= L(r_I, k) L(r_J, k)' for the tiles I >= J below the diagonal of every
+// column of the step.  Workgroup e = wg[blockIdx.x] = {slot of L(r_I, k), slot of L(r_J, k), destination slot}: the pairs and their
+// destinations are listed once, in the symbolic phase (the tile map for a destination inside the matrix; for a column of an arc whose
+// update lands in separator x separator tiles, or in the right-hand side of a separator column, the arc's PRIVATE tile: two arcs of
+// one step would otherwise add to the same tile at the same time; k_tchol_merge adds the private tiles to the matrix once all arcs
+// are done).
+__global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles, const int4* __restrict__ wg /*of this step*/) {
   __shared__ double bt[kNB][kNB + 1];
-  const int I = blockIdx.y, J = blockIdx.x;
-  if (J > I) return;
-  const int rI = rows[I], rJ = rows[J];
-  if (rJ >= nT) return;                       // the right-hand-side row is never a column
-  const int32_t dslot = (smap != nullptr && rJ >= sep0) ? smap[(size_t)(rI - sep0) * (nT - sep0) + (rJ - sep0)] : map[(size_t)rI * nT + rJ];
-  if (dslot < 0) return;                      // cannot happen after symbolic fill; never write through a bad slot
-  const double* A = tiles + (size_t)slots[I] * 4096;
-  const double* B = tiles + (size_t)slots[J] * 4096;
-  double* Dt = tiles + (size_t)dslot * 4096;
+  const int4 e = wg[blockIdx.x];
+  const double* A = tiles + (size_t)e.x * 4096;
+  const double* B = tiles + (size_t)e.y * 4096;
+  double* Dt = tiles + (size_t)e.z * 4096;
   const int tid = threadIdx.x;
   const int l = tid & 63, wv = tid >> 6;
   const int ar = l & 15, ak = l >> 4;
@@ -267,24 +265,27 @@ __global__ void k_tchol_unperm(int n_cam, const double* __restrict__ xp, const i
   x[i] = xp[(size_t)pos[g] * 64 + 9 * (cam - kTileCams * g) + (i - 9 * cam)];
 }
 
-// backward step k of L' x = y.  x_k = W_k y_k (W_k = L_kk^-T from the column's first launch) comes from the launch before
-// this one when have_x is set, else every workgroup (one wave) forms it; then workgroup b takes tile (k, J_b) of tile row k:
-// y_J -= L(k, J)' x_k.  Workgroup `ahead` (or -1) holds the tile with J = k - 1: after its update y_(k-1) is final (the rows
-// above k were applied by earlier launches), so it goes on to x_(k-1) = W_(k-1) y_(k-1) with W requested at the start, and
-// the next launch finds it in memory instead of waiting for W and y itself.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_bwd(const double* __restrict__ tiles, int k, int n_row_tiles, const int32_t* __restrict__ cols,
-                                                  const int32_t* __restrict__ slots, const double* __restrict__ Winv_all, double* __restrict__ y,
-                                                  double* __restrict__ x, int have_x, int ahead) {
+// Backward step of L' x = y, one tile row of every arc per launch (a separator row alone).  Workgroup e = wg[blockIdx.x] = {row k, slot
+// of its tile (k, J) or -1 when the row has no tile (then the workgroup only forms x_k), column J, flags}.  x_k = W_k y_k (W_k = L_kk^-T
+// from the column's first launch) comes from the launch before this one when flag 1 is set, else every workgroup (one wave) forms it;
+// then the workgroup takes its tile: y_J -= L(k, J)' x_k.  The workgroup with flag 2 holds the tile with J = k - 1: after its update
+// y_(k-1) is final (the rows above k were applied by earlier launches), so it goes on to x_(k-1) = W_(k-1) y_(k-1) with W requested
+// at the start, and the next launch finds it in memory instead of waiting for W and y itself.  Flag 4: the row's first workgroup
+// (it stores x_k).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_bwd(const double* __restrict__ tiles, const int4* __restrict__ wg /*of this step*/,
+                                                  const double* __restrict__ Winv_all, double* __restrict__ y, double* __restrict__ x) {
   __shared__ double ys[kNB];
   __shared__ double xk[kNB];
   const int tid = threadIdx.x;
-  const bool lead = (int)blockIdx.x == ahead;
-  const bool work = (int)blockIdx.x < n_row_tiles;
+  const int4 e = wg[blockIdx.x];
+  const int k = e.x;
+  const bool work = e.y >= 0;
+  const bool have_x = (e.w & 1) != 0, lead = (e.w & 2) != 0, first = (e.w & 4) != 0;
   // everything the step reads is requested before the first wait: the tile (one column per lane), the entry of y it updates,
   // W of the next step in the workgroup that runs ahead.  (Left to the compiler the tile's loads came one by one, each
   // waited for before the next: the 64 FMAs form one chain, and it saw no reason to keep registers for loads in flight.)
-  const double* T = tiles + (size_t)(work ? slots[blockIdx.x] : 0) * 4096;   // (a row without tiles has no list to read)
-  const int col = work ? cols[blockIdx.x] : 0;
+  const double* T = tiles + (size_t)(work ? e.y : 0) * 4096;
+  const int col = work ? e.z : 0;
   double tv[kNB], wn[kNB];
   double y_old = 0.0;
   if (work) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int c = 0; c < kNB; ++c) xv = fma(wk[c], ys[c], xv);
     xk[tid] = xv;
-    if (blockIdx.x == 0) x[k * kNB + tid] = xv;
+    if (first) x[k * kNB + tid] = xv;
   }
   __syncthreads();
   if (!work) return;

@@ -184,13 +184,13 @@ def plan_tile_order(n_rows, edges_u, edges_v, n_arcs):
     eu = np.ascontiguousarray(edges_u, dtype=np.int32)
     ev = np.ascontiguousarray(edges_v, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)
-    arc = np.zeros(5, dtype=np.int32)
-    na, fill = C.c_int32(0), C.c_int64(0)
+    arc = np.zeros(n_arcs + 1, dtype=np.int32)
+    na, fill, cost = C.c_int32(0), C.c_int64(0), C.c_double(0.0)
     rc = lib().miba_plan_tile_order(C.c_int32(n_rows), _ip(eu), _ip(ev), C.c_int64(eu.size), C.c_int32(n_arcs), _ip(pos), _ip(arc),
-                                    C.byref(na), C.byref(fill))
+                                    C.byref(na), C.byref(fill), C.byref(cost))
     if rc != 0:
         raise MibaError("miba_plan_tile_order rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
-    return dict(pos=pos, arc_start=[int(a) for a in arc[:na.value + 1]], n_arcs=na.value, fill_tiles=fill.value)
+    return dict(pos=pos, arc_start=[int(a) for a in arc[:na.value + 1]], n_arcs=na.value, fill_tiles=fill.value, cost_us=cost.value)
 
 
 def plan_product_stats(n_cam, n_pt, obs_cam, obs_pt, obs_xy):

@@ -26,7 +26,10 @@ class env:
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.kw}
         for k, v in self.kw.items():
-            os.environ[k] = v
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
     def __exit__(self, *a):
         for k, v in self.old.items():
@@ -76,18 +79,20 @@ def test_tiles_equal_dense(shape, assembly):
     assert abs(a["model_cost_change"] - b["model_cost_change"]) <= 1e-11 * abs(b["model_cost_change"])
 
 
-@pytest.mark.parametrize("shape,arcs", [("ring-300", 2), ("ring-300", 3), ("ring-1500", 4), ("scrambled-300", 3), ("ring-1500", 1)])
+@pytest.mark.parametrize("shape,arcs", [("ring-300", 2), ("ring-300", 3), ("ring-1500", 4), ("scrambled-300", 3), ("ring-1500", 1), ("ring-1500", 8),
+                                        ("ring-2000", 0)])
 def test_dissected_order_equals_dense(shape, arcs):
-    """the tile rows cut into arcs that are factored side by side on several streams, their separator updates collected in private
-    tiles and merged (csrc/miba.hip: sparse_symbolic, sparse_solve): the same step as the dense factorisation.  A scrambled camera
-    numbering has no small separator: the order falls back to plain minimum degree on one stream (and must still be right)."""
+    """the tile rows cut into arcs that are factored side by side (every launch takes one column of every arc), their separator updates
+    collected in private tiles and merged (csrc/miba.hip: sparse_symbolic, sparse_solve): the same step as the dense factorisation.
+    A scrambled camera numbering has no small separator: the order falls back to plain minimum degree (and must still be right).
+    arcs = 0: the number of arcs the symbolic phase chooses by its cost model."""
     kind, n_cam = shape.split("-")
     n_cam = int(n_cam)
     pr = synth.make_problem(n_cam, 40 * n_cam, 170 * n_cam, seed=n_cam)
     if kind == "scrambled":
         pr, _ = _scrambled(pr, 5)
     cams0, pts0 = synth.perturb(pr, 0.003, 0.05, seed=3)
-    with env(MIBA_SPARSE_ARCS=str(arcs)):
+    with env(MIBA_SPARSE_ARCS=str(arcs) if arcs else None):
         a = _step(pr, cams0, pts0, 1e4, "sparse")
         a2 = _step(pr, cams0, pts0, 1e4, "sparse")
     b = _step(pr, cams0, pts0, 1e4, "dense")
@@ -138,7 +143,7 @@ def test_tiles_on_two_ranks():
 
 
 def test_dissected_order_on_two_ranks():
-    """every rank factors the united tiles with its own three streams; the ranks' private tiles and merge lists are the same"""
+    """every rank factors the united tiles, three arcs side by side; the ranks' private tiles and merge lists are the same"""
     pr = synth.make_problem(1500, 60000, 255000, seed=1500)
     cams0, pts0 = synth.perturb(pr, 0.003, 0.05, seed=3)
     with env(MIBA_SPARSE_ARCS="3"):

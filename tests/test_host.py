@@ -241,7 +241,8 @@ def _symbolic_fill(n, eu, ev, pos):
     return cols, fill
 
 
-@pytest.mark.parametrize("shape,n,w,arcs", [("ring", 400, 6, 3), ("band", 300, 4, 4), ("ring", 257, 9, 2), ("ring", 120, 5, 1)])
+@pytest.mark.parametrize("shape,n,w,arcs", [("ring", 400, 6, 3), ("band", 300, 4, 4), ("ring", 257, 9, 2), ("ring", 120, 5, 1), ("ring", 1500, 5, 12),
+                                            ("band", 1200, 3, 32)])
 def test_tile_order_dissects_bands_and_rings(shape, n, w, arcs):
     """the exact solve's elimination order (csrc/miba_plan.hpp, order_tile_graph; what Ceres' ordering does behind ceres::Solve at
     src/BundleAdjustment.cpp:108 for SPARSE_SCHUR): a permutation; the arcs' steps are contiguous and come before the separator's;
@@ -266,6 +267,10 @@ def test_tile_order_dissects_bands_and_rings(shape, n, w, arcs):
         # (an arc carries the separator rows of its low end along, as the plain order of a RING carries the rows that close it: about
         # the same fill on a ring, up to twice a plain band's)
         assert r["fill_tiles"] <= (1.25 if shape == "ring" else 2.0) * plain["fill_tiles"]
+        # the model the symbolic phase chooses the number of arcs by (tile_order_cost): shorter chains of launches are cheaper
+        assert r["cost_us"] < plain["cost_us"]
+        longest = max(b - a for a, b in zip(st, st[1:]))
+        assert r["cost_us"] >= 35.0 * (longest + n - st[-1]) - 1e-6
 
 
 def test_tile_order_without_locality_is_not_dissected():
