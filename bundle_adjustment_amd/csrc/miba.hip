@@ -1472,7 +1472,7 @@ int sparse_symbolic(miba_handle h) {
       n_wg += m + m * (m - 1) / 2;   // (the right-hand-side row is never a column: m - 1 columns, pairs I >= J)
     }
   n_wg += n_off + nT;
-  if ((double)n_wg * sizeof(int4) > free_all / 8) return MIBA_OK;   // the lists do not fit
+  if ((double)n_wg * sizeof(int4) > std::min(free_all / 8, 4e9)) return MIBA_OK;   // the lists (built on the host first) do not fit: PCG stands in
   std::vector<int4> wg;
   wg.reserve((size_t)n_wg);
   for (auto& ks : fwd_cols) {
