@@ -1562,8 +1562,12 @@ int sparse_symbolic(miba_handle h) {
     if (!merge_dst.empty() && (rc = upload(h, h->d_sp_merge_dst, merge_dst.data(), merge_dst.size()))) return rc;
   }
   if (h->cfg.log_level > 0 || getenv("MIBA_SPARSE_DEBUG"))
-    fprintf(stderr, "[miba] tile factorisation: %d tile rows, %lld tiles below the diagonal after fill, %d arc(s), %d separator rows, %lld private tiles\n",
-            nT, (long long)n_off, n_arcs, nS, (long long)n_priv);
+  {
+    int64_t n_pairs = 0;
+    for (const miba_handle_s::SpStep& S : h->sp_fwd) n_pairs += S.n_upd;
+    fprintf(stderr, "[miba] tile factorisation: %d tile rows, %lld tiles below the diagonal after fill, %d arc(s), %d separator rows, %lld private tiles, "
+            "%zu forward steps, %lld tile products\n", nT, (long long)n_off, n_arcs, nS, (long long)n_priv, h->sp_fwd.size(), (long long)n_pairs);
+  }
   if (!h->dense_plan_tried && (rc = dense_plan(h))) return rc;
   h->sparse_state = 1;
   return MIBA_OK;
