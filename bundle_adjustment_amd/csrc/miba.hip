@@ -1346,8 +1346,10 @@ int sparse_symbolic(miba_handle h) {
     auto order_one = [&](size_t i) {
       Cand& c = cs[i];
       c.got = cand[i];
-      c.ok = order_tile_graph(c.adj, nT, cand[i], max_tiles, h->cfg.log_level, c.got, c.grp, c.pos, c.nodes, c.arc, c.off);
-      if (c.ok) c.cost = tile_order_cost(c.nodes, c.arc, c.got, nT);
+      try {   // (a host thread: nothing may leave it)
+        c.ok = order_tile_graph(c.adj, nT, cand[i], max_tiles, h->cfg.log_level, c.got, c.grp, c.pos, c.nodes, c.arc, c.off);
+        if (c.ok) c.cost = tile_order_cost(c.nodes, c.arc, c.got, nT);
+      } catch (...) { c.ok = false; }
     };
     {
       std::vector<std::thread> th;
