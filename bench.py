@@ -235,6 +235,9 @@ def main():
                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None,
                     "traffic_bytes_pmc": rec.get("traffic_bytes_per_launch"),
                     "valu_busy_frac_pmc": rec.get("valu_busy_frac"), "lds_busy_frac_pmc": rec.get("lds_busy_frac")}
+        if kid == miba.K_EVAL_COST and n <= 1:
+            kern[nm]["note"] = ("not launched inside the LM iterations: the back-substitution takes the candidate's cost along "
+                                "(k_mf_backsub_cm, csrc/miba_mf2.hpp; MIBA_K1_FOLD=0 keeps the kernels apart)")
     red_n = kt["launches"][miba.K_CAM_REDUCE]
     red_ms = kt["total_ms"][miba.K_CAM_REDUCE] / red_n if red_n else None
     rec3 = pmc_of(miba.K_SCHUR_MATVEC)

@@ -210,6 +210,7 @@ struct miba_handle_s {
   bool dense_planned = false, dense_plan_tried = false;
   // tile-sparse exact solve (miba_sparse.hpp), built on first use: tiles of the lower block triangle of S + the right-hand-side
   // tile row, tile map, ordering (pos: camera group -> tile row, grp: its inverse), per-column and per-row tile lists
+  bool k1_fold = true, cand_cost_done = false;   // candidate cost inside the back-substitution (backsub_and_candidate)
   int sparse_state = 0;            // 0 not tried, 1 ready, -1 the pattern does not fit (PCG to eta_exact stands in)
   int sp_nT = 0;
   int64_t sp_n_mat = 0;            // tiles of the matrix; the right-hand-side tiles follow them
@@ -508,7 +509,7 @@ int eval_cost(miba_handle h, const double* cam, const double* X, bool reduce = t
     Timed t(h, MIBA_K_EVAL_COST);
 #define MIBA_COST_ARGS                                                                                                   \
   dim3((unsigned)(h->n_tiles + h->n_giant)), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant, h->d_grps,   \
-      h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct_cand, X, h->d_part_tile, h->loss
+      h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct_cand, X, h->d_part_tile, h->loss, 1, 0
     if (h->loss.type != kLossNone) hipLaunchKernelGGL(k_mf_cost<true>, MIBA_COST_ARGS);
     else hipLaunchKernelGGL(k_mf_cost<false>, MIBA_COST_ARGS);
 #undef MIBA_COST_ARGS
@@ -1632,7 +1633,27 @@ int linear_solve(miba_handle h, const miba_options* o, int* n_it, int* status) {
 
 // back-substitution, candidate state, model cost change, step / candidate norms
 // reduce = false: the caller all-reduces S_MCC, S_DP2, S_XP2 itself (together with the candidate cost)
-int backsub_and_candidate(miba_handle h, bool reduce = true) {
+// with_cost: the caller wants the candidate's cost in S_COST next (the LM loop).  Where the camera-major kernel runs it takes the cost
+// along (k_mf_backsub_cm: the candidate cameras and their tables are formed first, they depend on the PCG's solution alone) and
+// h->cand_cost_done tells the caller that eval_cost is not needed; MIBA_K1_FOLD=0 keeps the two kernels apart.
+int backsub_and_candidate(miba_handle h, bool reduce = true, bool with_cost = false) {
+  const bool cm = h->loss.type == kLossNone && h->k3_cm && h->d_oxy_cm && !h->k4_pm;
+  const bool fold = with_cost && cm && h->k1_fold && h->n_tiles > 0;
+  h->cand_cost_done = false;
+  auto cam_candidate = [&]() -> int {
+    const int nb = 120;
+    hipLaunchKernelGGL(k_cam_update, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_cam, h->d_sc, h->d_px, h->d_cam_active,
+                       h->d_cam_cand, h->d_part_small);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 0, 0, h->d_sum + S_DC2);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 1, 0, h->d_sum + S_XC2);
+    HIPCHK(h, hipGetLastError());
+    return MIBA_OK;
+  };
+  int rc;
+  if (fold) {
+    if ((rc = cam_candidate())) return rc;
+    if ((rc = launch_cam_tables(h, h->d_cam_cand, true))) return rc;
+  }
   {
     if (h->n_tiles) {
       Timed t(h, MIBA_K_BACKSUB);
@@ -1643,31 +1664,35 @@ int backsub_and_candidate(miba_handle h, bool reduce = true) {
         hipLaunchKernelGGL((k_mf_backsub<false, true>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));
         if (h->n_giant) hipLaunchKernelGGL((k_mf_backsub<true, true>), MIBA_BACKSUB_ARGS(h->n_giant, h->d_giant));
       } else {
-        if (h->k3_cm && h->d_oxy_cm && !h->k4_pm)
+        if (cm)
           hipLaunchKernelGGL(k_mf_backsub_cm, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_oxy, h->d_ct, h->d_cm,
                              h->d_sc, h->d_sp, h->d_ptrec, h->d_px, h->d_yp, h->d_Xc, h->d_part_tile,
-                             CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64, nullptr}, (const double2*)h->d_oxy_cm);
+                             CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64, nullptr}, (const double2*)h->d_oxy_cm,
+                             fold ? (const double*)h->d_ct_cand : (const double*)nullptr);
         else hipLaunchKernelGGL((k_mf_backsub<false, false>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));
         if (h->n_giant) hipLaunchKernelGGL((k_mf_backsub<true, false>), MIBA_BACKSUB_ARGS(h->n_giant, h->d_giant));
       }
 #undef MIBA_BACKSUB_ARGS
+      // the giant tiles' candidate cost into the free column of their partial sums (behind their back-substitution, which clears it)
+      if (fold && h->n_giant)
+        hipLaunchKernelGGL(k_mf_cost<false>, dim3((unsigned)h->n_giant), dim3(kChunk), 0, h->st, (int)h->n_giant, h->d_tiles, h->d_giant, h->d_grps,
+                           h->d_idx, h->d_ocam, h->d_wl, h->d_tile_cams, h->d_oxy, h->d_ct_cand, h->d_Xc, h->d_part_tile, h->loss, 4, 3);
     }
   }
   HIPCHK(h, hipGetLastError());
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 0, 0, h->d_sum + S_MCC);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 1, 0, h->d_sum + S_DP2);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 2, 0, h->d_sum + S_XP2);
+  if (fold) {
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_tile, (size_t)h->n_tiles, 4, 3, 0, h->d_sum + S_COST);
+    h->cand_cost_done = true;
+  }
   HIPCHK(h, hipGetLastError());
   if (reduce) {
-    int rc = allreduce(h, h->d_sum + S_MCC, 3, ncclSum);  // S_MCC, S_DP2, S_XP2 are adjacent
+    rc = allreduce(h, h->d_sum + S_MCC, 3, ncclSum);  // S_MCC, S_DP2, S_XP2 are adjacent
     if (rc) return rc;
   }
-  const int nb = 120;
-  hipLaunchKernelGGL(k_cam_update, dim3(nb), dim3(256), 0, h->st, h->n_cam, h->d_cam, h->d_sc, h->d_px, h->d_cam_active,
-                     h->d_cam_cand, h->d_part_small);
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 0, 0, h->d_sum + S_DC2);
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, h->st, h->d_part_small, (size_t)nb, 2, 1, 0, h->d_sum + S_XC2);
-  HIPCHK(h, hipGetLastError());
+  if (!fold && (rc = cam_candidate())) return rc;
   return MIBA_OK;
 }
 
@@ -1862,6 +1887,7 @@ static int create_impl(const miba_config* cfg, bool make_comm, miba_handle* out)
   if (const char* te = getenv("MIBA_TAIL_SPLIT")) h->tail_split = te[0] == '1';
   if (const char* te = getenv("MIBA_XCD_REMAP")) h->xcd_remap = h->k3_remap = te[0] != '0';
   if (const char* te = getenv("MIBA_K4")) h->k4_pm = !strcmp(te, "pm");   // the point-major back-substitution on every tile (tests, A/B)
+  if (const char* te = getenv("MIBA_K1_FOLD")) h->k1_fold = te[0] != '0';   // 0: the candidate's cost by its own kernel (tests, A/B)
   if (const char* te = getenv("MIBA_TAIL_TIMEOUT_TICKS")) { const long long v = atoll(te); if (v >= 1) h->tail_timeout = v; }
   if (e != hipSuccess) {
     int rc = fail(nullptr, MIBA_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
@@ -3253,12 +3279,14 @@ int miba_solve(miba_handle h, const miba_options* opt, miba_iteration_callback c
     // valid): its partial sum sits next to those of the back-substitution, so one all-reduce of four scalars and one
     // host read serve both.
     if (snap_on && (rc = snapshot_guard(h))) return rc;
-    rc = backsub_and_candidate(h, false);
+    rc = backsub_and_candidate(h, false, true);
     if (rc) return rc;
     t_linear += now_s() - tl;
     const double tr = now_s();
-    rc = eval_cost(h, h->d_cam_cand, h->d_Xc, false);
-    if (rc) return rc;
+    if (!h->cand_cost_done) {   // (else the back-substitution has taken the candidate's cost along)
+      rc = eval_cost(h, h->d_cam_cand, h->d_Xc, false);
+      if (rc) return rc;
+    }
     static_assert(S_COST + 1 == S_MCC && S_MCC + 1 == S_DP2 && S_DP2 + 1 == S_XP2, "scalar slots must be adjacent");
     rc = allreduce(h, h->d_sum + S_COST, 4, ncclSum);
     if (rc) return rc;

@@ -959,13 +959,69 @@ __global__ __launch_bounds__(256) void k_mf_backsub(const Tile* __restrict__ til
 // cameras (R, t, f, k1, k2) are staged in LDS, every lane gathers its point and reads its measurement.
 // The first n_giant blocks take the giant tiles of tile_list, block n_giant + i takes tile i.
 constexpr int kCamCost = 16;   // 15 doubles used: 8 x ds_read_b128
+
+// |r|^2 of one observation of the camera record cd (R 0..8, t 9..11, f 12, k1 13, k2 14) at the point x
+__device__ __forceinline__ double mf_cost_obs(const double* cd, const double x0, const double x1, const double x2, const double ox, const double oy) {
+  const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
+  const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
+  const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
+  const double iz = mf_rcp(P2);
+  const double px = -P0 * iz, py = -P1 * iz;
+  const double n = px * px + py * py;
+  const double d = 1.0 + n * (cd[13] + cd[14] * n);
+  const double r0 = cd[12] * d * px - ox, r1 = cd[12] * d * py - oy;
+  return r0 * r0 + r1 * r1;
+}
+
+__device__ __forceinline__ void mf_read_cam_cost(double* cd, const double* s_cam16, const int cs) {
+  const double2* c2 = reinterpret_cast<const double2*>(s_cam16) + (kCamCost / 2) * cs;
+#pragma unroll
+  for (int k = 0; k < kCamCost / 2; ++k) { const double2 v = c2[k]; cd[2 * k] = v.x; cd[2 * k + 1] = v.y; }
+}
+
+// sum of |r|^2 (rho(|r|^2) with a loss) over this thread's observations of the non-giant tile t, cameras staged in s_cam16.
+// FRESH: the points were written by this workgroup earlier in the same launch (k_mf_backsub_cm's point-major tiles): read past the
+// compute unit's vector cache.
+template <bool LOSS, bool FRESH>
+__device__ __forceinline__ double mf_cost_tile(const Tile& t, const int32_t* __restrict__ idx, const int2* __restrict__ wl, const double* __restrict__ oxy,
+                                               const double* s_cam16, const double* X, const Loss& loss) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nwl = t.nslot / kWave;
+  double cost = 0.0;
+  for (int q = wv; q < nwl; q += 4) {
+    const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
+    const int32_t w = idx[slot];
+    if (w < 0) continue;
+    const size_t p = (size_t)(wl[(t.slot0 >> 6) + q].x + (w & 0xFF));
+    double x0, x1, x2;
+    if (FRESH) {
+      x0 = __hip_atomic_load(X + 3 * p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      x1 = __hip_atomic_load(X + 3 * p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      x2 = __hip_atomic_load(X + 3 * p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      x0 = X[3 * p]; x1 = X[3 * p + 1]; x2 = X[3 * p + 2];
+    }
+    const size_t chunk = slot / kChunk, l = slot % kChunk;
+    const double ox = oxy[chunk * (2 * kChunk) + l], oy = oxy[chunk * (2 * kChunk) + kChunk + l];
+    double cd[kCamCost];
+    mf_read_cam_cost(cd, s_cam16, (w >> 8) & 0xFF);
+    double rho = mf_cost_obs(cd, x0, x1, x2, ox, oy);
+    if (LOSS) { double om; mf_loss(loss, rho, rho, om); }
+    cost += rho;
+  }
+  return cost;
+}
+
+// partial_cost[tile * pstride + poff] = the tile's cost (pstride 1, poff 0: a vector of its own; 4, 3: the free column of the
+// back-substitution's partial sums, when that kernel has taken the other tiles' candidate cost along)
 template <bool LOSS>
 __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __restrict__ tiles, const int32_t* __restrict__ tile_list,
                                                  const Group* __restrict__ grps, const int32_t* __restrict__ idx,
                                                  const int32_t* __restrict__ ocam, const int2* __restrict__ wl,
                                                  const int32_t* __restrict__ tile_cams, const double* __restrict__ oxy,
                                                  const double* __restrict__ ct, const double* __restrict__ X,
-                                                 double* __restrict__ partial_cost, const Loss loss) {
+                                                 double* __restrict__ partial_cost, const Loss loss, const int pstride, const int poff) {
   __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamCost];
   __shared__ double s4[4];
   const bool giant = (int)blockIdx.x < n_giant;
@@ -981,32 +1037,7 @@ __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __rest
       for (int k = 0; k < 15; ++k) s_cam[kCamCost * tid + k] = T[k];
     }
     __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
-    const int nwl = t.nslot / kWave;
-    for (int q = wv; q < nwl; q += 4) {
-      const size_t slot = (size_t)t.slot0 + (size_t)q * kWave + lane;
-      const int32_t w = idx[slot];
-      if (w < 0) continue;
-      const size_t p = (size_t)(wl[(t.slot0 >> 6) + q].x + (w & 0xFF));
-      const double x0 = X[3 * p], x1 = X[3 * p + 1], x2 = X[3 * p + 2];
-      const size_t chunk = slot / kChunk, l = slot % kChunk;
-      const double ox = oxy[chunk * (2 * kChunk) + l], oy = oxy[chunk * (2 * kChunk) + kChunk + l];
-      const double2* c2 = reinterpret_cast<const double2*>(s_cam) + (kCamCost / 2) * ((w >> 8) & 0xFF);
-      double cd[kCamCost];
-#pragma unroll
-      for (int k = 0; k < kCamCost / 2; ++k) { const double2 v = c2[k]; cd[2 * k] = v.x; cd[2 * k + 1] = v.y; }
-      const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
-      const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
-      const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
-      const double iz = mf_rcp(P2);
-      const double px = -P0 * iz, py = -P1 * iz;
-      const double n = px * px + py * py;
-      const double d = 1.0 + n * (cd[13] + cd[14] * n);
-      const double r0 = cd[12] * d * px - ox, r1 = cd[12] * d * py - oy;
-      double rho = r0 * r0 + r1 * r1;
-      if (LOSS) { double om; mf_loss(loss, rho, rho, om); }
-      cost += rho;
-    }
+    cost = mf_cost_tile<LOSS, false>(t, idx, wl, oxy, s_cam, X, loss);
   } else {
     for (int gi = 0; gi < t.ngrp; ++gi) {
       const Group G = grps[t.grp0 + gi];
@@ -1017,22 +1048,14 @@ __global__ __launch_bounds__(256) void k_mf_cost(int n_giant, const Tile* __rest
         const size_t slot = chunk * kChunk + tid;
         if (idx[slot] < 0) continue;
         const double* cd = ct + (size_t)kCamTabStride * ocam[slot];
-        const double P0 = cd[0] * x0 + cd[1] * x1 + cd[2] * x2 + cd[9];
-        const double P1 = cd[3] * x0 + cd[4] * x1 + cd[5] * x2 + cd[10];
-        const double P2 = cd[6] * x0 + cd[7] * x1 + cd[8] * x2 + cd[11];
-        const double iz = mf_rcp(P2);
-        const double px = -P0 * iz, py = -P1 * iz;
-        const double n = px * px + py * py;
-        const double d = 1.0 + n * (cd[13] + cd[14] * n);
-        const double r0 = cd[12] * d * px - oxy[chunk * (2 * kChunk) + tid], r1 = cd[12] * d * py - oxy[chunk * (2 * kChunk) + kChunk + tid];
-        double rho = r0 * r0 + r1 * r1;
+        double rho = mf_cost_obs(cd, x0, x1, x2, oxy[chunk * (2 * kChunk) + tid], oxy[chunk * (2 * kChunk) + kChunk + tid]);
         if (LOSS) { double om; mf_loss(loss, rho, rho, om); }
         cost += rho;
       }
     }
   }
   const double tot = block_sum(cost, s4);
-  if (tid == 0) partial_cost[tile_id] = 0.5 * tot;
+  if (tid == 0) partial_cost[(size_t)tile_id * pstride + poff] = 0.5 * tot;
 }
 
 // Jacobi scale from the raw (unit-scale) camera sums: sc = 1 / (1 + sqrt(diag F'F))

@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256, MIBA_CM_WAVES) void k_mf_matvec_cm(int n_giant
 // observations and the point sums are three LDS adds.  The measurements come in camera-major order (oxy_cm, gathered once per problem
 // through the layout's source slots).  Tiles with a camera in the small-angle branch or without a layout take mf_backsub_tile
 // (miba_mf.hpp) inside the same launch; giant tiles keep their own launch (k_mf_backsub<true, .>), solves with a loss the old kernel.
+// THE CANDIDATE COST RIDES ALONG (ct_cand != null: the camera tables of the candidate cameras, which depend on the PCG's solution
+// alone and are written before this launch): phase 1.5 leaves the candidate point in the X slots of the sub-tile's LDS buffer,
+// phase 2 projects it through the candidate camera and adds |r|^2 — what the cost kernel K1' (k_mf_cost) would read the index
+// words, the measurements and the points a second time for (0.17 ms at Final-13682).  The tile's cost goes to partial[4 ti + 3].
 
 // measurements of the camera-major entries: out[entry] = (ox, oy) of the observation in local slot src[entry]; padding entries get 0
 __global__ void k_cm_gather_oxy(int64_t n_entries, const int32_t* __restrict__ src, const double* __restrict__ oxy, double2* __restrict__ out) {
@@ -332,8 +336,9 @@ __global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Ti
                                                           const double* __restrict__ sc, const double* __restrict__ sp,
                                                           const double* __restrict__ ptrec, const double* __restrict__ yc,
                                                           double* __restrict__ yp, double* __restrict__ Xc, double* __restrict__ partial,
-                                                          const CmArgs A, const double2* __restrict__ oxy_cm) {
+                                                          const CmArgs A, const double2* __restrict__ oxy_cm, const double* __restrict__ ct_cand) {
   __shared__ __align__(16) double s_cam[kMaxCamSlots * kCamLds];
+  __shared__ __align__(16) double s_cam2[kMaxCamSlots * kCamCost];   // the candidate cameras: R, t, f, k1, k2
   __shared__ __align__(16) double s_pt[2 * kCmPtBuf];
   __shared__ double s4[4];
   const int ti = blockIdx.x, tid = threadIdx.x;
@@ -345,11 +350,20 @@ __global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Ti
   if (tid < t.ncs) {
     mf_stage_cam(s_cam + kCamLds * tid, c64.x, ct, cm, sc, yc);
     small = s_cam[kCamLds * tid + 24] != 0.0;
+    if (ct_cand) {
+      const double* T = ct_cand + (size_t)kCamTabStride * c64.x;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) s_cam2[kCamCost * tid + k] = T[k];
+    }
   }
-  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0;
+  double mcc = 0.0, dp2 = 0.0, xp2 = 0.0, cost = 0.0;
   const int any_small = __syncthreads_or(small || ctile.nsub == 0);
   if (any_small) {
     mf_backsub_tile<false>(t, idx, wl, oxy, sp, ptrec, s_cam, yp, Xc, nullptr, mcc, dp2, xp2);
+    if (ct_cand) {
+      __syncthreads();   // the tile's candidate points are in memory
+      cost = mf_cost_tile<false, true>(t, idx, wl, oxy, s_cam2, Xc, Loss{kLossNone, 0.0});
+    }
   } else {
     auto stage_write = [&](double* buf, const int sl, const double x0, const double x1, const double x2, const bool on) {
       if (on) {
@@ -439,10 +453,11 @@ __global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Ti
         const double d0 = x0 - c0, d1 = x1 - c1, d2 = x2 - c2;   // step norm exactly as Ceres: |x - x_cand|
         dp2 += d0 * d0 + d1 * d1 + d2 * d2;
         xp2 += c0 * c0 + c1 * c1 + c2 * c2;
+        pp[0] = c0; pp[kCmMaxPts] = c1; pp[2 * kCmMaxPts] = c2;   // (X has done its work in this sub-tile: phase 2 projects the candidate)
       }
       stage_write(buf_next, slot_next, nx0, nx1, nx2, on_n);
       __syncthreads();
-      // ---- phase 2: m = u + E z, model cost change ----
+      // ---- phase 2: m = u + E z, model cost change; the candidate's residual ----
       if (seg_on) {
 #pragma unroll
         for (int j = 0; j < kCmSeg; ++j) {
@@ -451,6 +466,17 @@ __global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Ti
           const double m0 = su0[j] + sE[j][0] * z0 + sE[j][1] * z1 + sE[j][2] * z2;
           const double m1 = su1[j] + sE[j][3] * z0 + sE[j][4] * z1 + sE[j][5] * z2;
           if (e[j] & 0x8000u) mcc += m0 * ((sr0[j] - oo[j].x) - 0.5 * m0) + m1 * ((sr1[j] - oo[j].y) - 0.5 * m1);
+        }
+        if (ct_cand) {
+          double cd2[kCamCost];
+          mf_read_cam_cost(cd2, s_cam2, cs);
+#pragma unroll
+          for (int j = 0; j < kCmSeg; ++j) {
+            const double* pp = buf + (e[j] & 0xFF);
+            const double c0 = lds_read64(pp), c1 = lds_read64(pp + kCmMaxPts), c2 = lds_read64(pp + 2 * kCmMaxPts);
+            const double rho = mf_cost_obs(cd2, c0, c1, c2, oo[j].x, oo[j].y);
+            if (e[j] & 0x8000u) cost += rho;
+          }
         }
       }
       if (on_p) { yp[3 * pg] = z0 * mf_rcp(s0); yp[3 * pg + 1] = z1 * mf_rcp(s1); yp[3 * pg + 2] = z2 * mf_rcp(s2); }
@@ -462,11 +488,12 @@ __global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Ti
   const double q0 = block_sum(mcc, s4);
   const double q1 = block_sum(dp2, s4);
   const double q2 = block_sum(xp2, s4);
+  const double q3 = block_sum(cost, s4);
   if (tid == 0) {
     partial[4 * (size_t)ti + 0] = q0;
     partial[4 * (size_t)ti + 1] = q1;
     partial[4 * (size_t)ti + 2] = q2;
-    partial[4 * (size_t)ti + 3] = 0.0;
+    partial[4 * (size_t)ti + 3] = 0.5 * q3;
   }
 }
 

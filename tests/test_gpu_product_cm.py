@@ -204,3 +204,58 @@ def test_backsubstitution_over_subtiles_equals_point_major(wide, monkeypatch, ch
     ca, cb = np.array([r["cost"] for r in res["cm"][1]]), np.array([r["cost"] for r in res["pm"][1]])
     assert len(ca) == len(cb) and np.abs(ca - cb).max() <= 1e-10 * cb[0]
     assert [r["step_is_successful"] for r in res["cm"][1]] == [r["step_is_successful"] for r in res["pm"][1]]
+
+
+@pytest.mark.parametrize("case", ["wide", "giant+small-angle"])
+def test_candidate_cost_inside_the_backsubstitution_equals_the_cost_kernel(oracle, wide, medium, monkeypatch, case):
+    """The LM loop's candidate cost (TrustRegionMinimizer: the cost at x + delta, behind ceres::Solve at src/BundleAdjustment.cpp:108)
+    taken along by k_mf_backsub_cm against the cost kernel K1' of the same library (MIBA_K1_FOLD=0), iteration by iteration, and
+    against the oracle's LM run; with a giant track (its tile's cost comes from k_mf_cost into the same partial sums) and cameras in the
+    small-angle branch (their tiles take the point-major code and the cost loop behind it inside the same launch)."""
+    monkeypatch.setenv("MIBA_K3", "cm")
+    if case == "wide":
+        pr, cams0, pts0 = wide
+        monkeypatch.setenv("MIBA_TILE_CHUNKS", "31")
+        oc, op, xy = pr["obs_cam"], pr["obs_pt"], pr["obs_xy"]
+    else:
+        pr, _, pts0 = medium
+        monkeypatch.setenv("MIBA_TILE_CHUNKS", "4")
+        oc, op = pr["obs_cam"].copy(), pr["obs_pt"].copy()
+        rng = np.random.default_rng(3)
+        op[rng.choice(oc.size, 150, replace=False)] = 7
+        # the scene with two cameras (nearly) unrotated and measured again, so that the LM run starts near a solution with those
+        # cameras inside the small-angle branch
+        cams = pr["cams"].copy()
+        cams[3, 0:3] = 0.0
+        cams[17, 0:3] = [1e-9, -2e-9, 5e-10]
+        xy, z = synth.project(cams, pr["pts"], oc, op)
+        ok = z < 0
+        oc, op, xy = oc[ok], op[ok], xy[ok] + rng.normal(0, 0.5, xy[ok].shape)
+        cams0 = cams.copy()
+        cams0[:, 3:6] += rng.normal(0, 0.01, (cams.shape[0], 3))
+    opt = dict(max_num_iterations=6, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("MIBA_K1_FOLD", fold)
+        s = miba.Solver(device_id=0)
+        s.set_problem(cams0, pts0, oc, op, xy)
+        assert s.kernel_times()["product_layout"] == 1
+        s.reset_kernel_times()
+        its, summ = s.solve(miba.default_options(**opt))
+        kt = s.kernel_times()
+        s.close()
+        res[fold] = its
+        # folded: the cost kernel runs for the initial cost only (and for nothing inside the iterations)
+        n_cost = kt["launches"][miba.K_EVAL_COST]
+        assert (n_cost <= 1) if fold == "1" else (n_cost >= len(its) - 1), (fold, n_cost)
+    a, b = res["1"], res["0"]
+    assert len(a) == len(b) == 7
+    for ra, rb in zip(a, b):
+        assert abs(ra["cost"] - rb["cost"]) <= 1e-12 * abs(rb["cost"]), (ra["iteration"], ra["cost"], rb["cost"])
+        assert abs(ra["cost_change"] - rb["cost_change"]) <= 1e-10 * abs(b[0]["cost"])
+        assert ra["step_is_successful"] == rb["step_is_successful"]
+        assert ra["linear_solver_iterations"] == rb["linear_solver_iterations"]
+    _, _, ref, _ = oracle.solve(cams0, pts0, oc, op, xy, oracle.default_options(linear_solver=oracle.ITERATIVE_SCHUR, num_threads=8, **opt))
+    assert len(ref) == len(a)
+    for ra, rr in zip(a, ref):
+        assert abs(ra["cost"] - rr["cost"]) <= 1e-9 * abs(rr["cost"]), (ra["iteration"], ra["cost"], rr["cost"])
