@@ -1156,7 +1156,7 @@ int reduced_assemble(miba_handle h, const SDst D, size_t n_clear, size_t n_reduc
   const bool loss = h->loss.type != kLossNone;   // the planned instance lists name no slots, the loss weights are per slot
   if (h->dense_planned && !loss) {
     if (h->n_dseg)
-      hipLaunchKernelGGL(k_dense_blocks, dim3(h->xcd_remap ? (nblk(h->n_dseg, 2) + 7) / 8 * 8 : nblk(h->n_dseg, 2)), dim3(256), 0, h->st, h->n_dseg,
+      hipLaunchKernelGGL(k_dense_blocks, dim3(h->xcd_remap ? (h->n_dseg + 7) / 8 * 8 : h->n_dseg), dim3(128), 0, h->st, h->n_dseg,
                          h->d_dseg, h->d_dpts, h->d_ct, h->d_cm, h->d_sc, h->d_ptrec, D, h->xcd_remap);
   } else if (h->n_tiles) {
 #define MIBA_PAIRS_ARGS dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_tile_cams, h->d_ct, h->d_cm, \

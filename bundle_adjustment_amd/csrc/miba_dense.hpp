@@ -309,15 +309,16 @@ __device__ __forceinline__ void dense_block_rows(const int lane, double* sr, con
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci, first, count, cj | atomic << 30}*/,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense_blocks(int n_seg, const int4* __restrict__ seg /*{ci, first, count, cj | atomic << 30}*/,
                                                       const int32_t* __restrict__ pts, const double* __restrict__ ct,
                                                       const double* __restrict__ cm, const double* __restrict__ sc,
                                                       const double* __restrict__ ptrec, const SDst D, const int xcd_remap) {
-  __shared__ double s_red[4][64 * 9];
+  __shared__ double s_red[2][64 * 9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // (XCD x takes the x-th eighth of the block-ordered segments: neighbouring blocks gather the same point records, see k_mf_camrows)
-  const int blk = xcd_remap ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int sg = blk * 2 + (wv >> 1);   // two waves per segment, half of the block's rows each
+  const int sg = xcd_remap ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  // one segment per workgroup, two waves, half of the block's rows each: a workgroup leaves when its segment is done (with two
+  // segments per workgroup the waves of the shorter one held their slots until the longer one had finished: 1.5 of 2 waves resident)
   if (sg >= n_seg) return;
   const int4 Sg = seg[sg];
   const int ci = __builtin_amdgcn_readfirstlane(Sg.x);
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int w4 = __builtin_amdgcn_readfirstlane(Sg.w);
   const int use_atomic = w4 >> 30, cj = w4 & 0x3FFFFFFF;
   const SBlock B = sdst_block(D, ci, cj);   // (wave-uniform, requested here: the lookups are back long before the stores)
-  if ((wv & 1) == 0) dense_block_rows<0, 5>(lane, s_red[wv], ci, cj, first, n, use_atomic, pts, ct, cm, sc, ptrec, B);
+  if (wv == 0) dense_block_rows<0, 5>(lane, s_red[wv], ci, cj, first, n, use_atomic, pts, ct, cm, sc, ptrec, B);
   else dense_block_rows<5, 9>(lane, s_red[wv], ci, cj, first, n, use_atomic, pts, ct, cm, sc, ptrec, B);
 }
 
