@@ -24,6 +24,7 @@ run MIBA_DENSE_PLAN=host || exit 1
 run MIBA_DEVICE_PLAN=0 || exit 1
 run MIBA_K3=pm || exit 1
 run MIBA_K4=pm || exit 1
+run MIBA_K1_FOLD=0 || exit 1
 run MIBA_TAIL_SPLIT=1 || exit 1
 run MIBA_SPARSE_ARCS=1 || exit 1
 run MIBA_SPARSE_ARCS=2 || exit 1
