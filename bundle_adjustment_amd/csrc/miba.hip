@@ -1474,33 +1474,63 @@ int sparse_symbolic(miba_handle h) {
       const int64_t m = col_ptr[k + 1] - col_ptr[k] - 1;
       n_wg += m + m * (m - 1) / 2;   // (the right-hand-side row is never a column: m - 1 columns, pairs I >= J)
     }
-  n_wg += n_off + nT;
+  n_wg += n_off + 2 * (int64_t)nT;
   if ((double)n_wg * sizeof(int4) > std::min(free_all / 8, 4e9)) return MIBA_OK;   // the lists (built on the host first) do not fit: PCG stands in
   std::vector<int4> wg;
   wg.reserve((size_t)n_wg);
-  for (auto& ks : fwd_cols) {
+  // pre[c]: the diagonal tile of column c is factored by the update launch of the step before (its workgroup for (c, c), listed
+  // first, has the tile's last update: column c - 1 of the same chain, one step earlier, holds row c) and k_tchol_col finds W in memory
+  std::vector<int32_t> step_of(nT, -1);
+  for (size_t st = 0; st < fwd_cols.size(); ++st)
+    for (int32_t k : fwd_cols[st]) step_of[k] = (int32_t)st;
+  const bool ahead_on = !(getenv("MIBA_SPARSE_AHEAD") && getenv("MIBA_SPARSE_AHEAD")[0] == '0');
+  std::vector<uint8_t> pre(nT + 1, 0);
+  for (size_t st = 0; st < fwd_cols.size(); ++st) {
+    const std::vector<int32_t>& ks = fwd_cols[st];
     miba_handle_s::SpStep S{(int64_t)wg.size(), 0, 0, 0};
     for (int32_t k : ks) {
       const int64_t c0 = col_ptr[k];
       const int m = (int)(col_ptr[k + 1] - c0) - 1;   // tiles below the diagonal, the right-hand-side tile among them
-      for (int b = 0; b < m; ++b) wg.push_back(int4{k, col_slots[c0 + 1 + b], k, b});
+      for (int b = 0; b < m; ++b) wg.push_back(int4{pre[k] ? -1 : k, col_slots[c0 + 1 + b], k, b});
     }
     S.n_col = (int32_t)(wg.size() - S.col0);
     S.upd0 = (int64_t)wg.size();
+    auto arc_map = [&](int32_t k) -> const int32_t* {
+      if (!(split && k < sep0)) return nullptr;
+      int a = 0;
+      while (k >= arc_start[a + 1]) ++a;
+      return smap.data() + (size_t)a * (nS + 1) * nS;
+    };
+    // the updates that complete the next step's diagonal tiles first: they have the longest way to go
     for (int32_t k : ks) {
       const int64_t c0 = col_ptr[k];
       const int m = (int)(col_ptr[k + 1] - c0) - 1;
       const int32_t* rows = col_rows.data() + c0 + 1;
       const int32_t* slots = col_slots.data() + c0 + 1;
-      const int32_t* sm = nullptr;
-      if (split && k < sep0) {
-        int a = 0;
-        while (k >= arc_start[a + 1]) ++a;
-        sm = smap.data() + (size_t)a * (nS + 1) * nS;
+      const bool to_private = arc_map(k) && k + 1 >= sep0;
+      if (ahead_on && m > 0 && rows[0] == k + 1 && k + 1 < nT && step_of[k + 1] == (int32_t)st + 1 && !to_private) {
+        pre[k + 1] = 1;
+        wg.push_back(int4{slots[0], slots[0], map[(size_t)(k + 1) * nT + (k + 1)], k + 2});
       }
+    }
+    // the other diagonal tiles of the next step were complete before this launch (no column of this step touches them): workgroups
+    // that only factor them.  Not the first separator column: the arcs' private tiles are merged into it behind this launch.
+    if (ahead_on && st + 1 < fwd_cols.size())
+      for (int32_t c : fwd_cols[st + 1])
+        if (!pre[c] && !(split && st + 1 == merge_at)) {
+          pre[c] = 1;
+          wg.push_back(int4{-1, -1, c, c + 1});
+        }
+    for (int32_t k : ks) {
+      const int64_t c0 = col_ptr[k];
+      const int m = (int)(col_ptr[k + 1] - c0) - 1;
+      const int32_t* rows = col_rows.data() + c0 + 1;
+      const int32_t* slots = col_slots.data() + c0 + 1;
+      const int32_t* sm = arc_map(k);
       for (int J = 0; J < m; ++J) {
         if (rows[J] >= nT) break;
         for (int I = J; I < m; ++I) {
+          if (I == 0 && J == 0 && pre[k + 1] && rows[0] == k + 1) continue;   // listed above
           const int32_t d = (sm && rows[J] >= sep0) ? sm[(size_t)(rows[I] - sep0) * nS + (rows[J] - sep0)] : map[(size_t)rows[I] * nT + rows[J]];
           if (d < 0) return fail(h, MIBA_ERR_INVALID, "tile (%d, %d) is missing from the fill of column %d", rows[I], rows[J], k);
           wg.push_back(int4{slots[I], slots[J], d, 0});
@@ -1596,7 +1626,7 @@ int sparse_solve(miba_handle h, int* status) {
                          (const int32_t*)h->d_sp_merge_dst);
     const miba_handle_s::SpStep& S = h->sp_fwd[i];
     hipLaunchKernelGGL(k_tchol_col, dim3(S.n_col), dim3(256), 0, h->st, T, (const int4*)(h->d_sp_wg + S.col0), h->d_sp_Ldiag, (int*)h->d_dflag);
-    if (S.n_upd) hipLaunchKernelGGL(k_tchol_update, dim3(S.n_upd), dim3(256), 0, h->st, T, (const int4*)(h->d_sp_wg + S.upd0));
+    if (S.n_upd) hipLaunchKernelGGL(k_tchol_update, dim3(S.n_upd), dim3(256), 0, h->st, T, (const int4*)(h->d_sp_wg + S.upd0), h->d_sp_Ldiag, (int*)h->d_dflag);
   }
   hipLaunchKernelGGL(k_tchol_gety, dim3(nb64), dim3(256), 0, h->st, nT, (const double*)T, (int)n_mat, h->d_sp_y);
   for (const miba_handle_s::SpStep& S : h->sp_bwd)

@@ -656,13 +656,14 @@ inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int
 
 
 // What the numeric phase pays for an order, in microseconds (sparse_symbolic chooses the number of arcs by it).  A forward step is two
-// dependent launches, column and update, for one column of every arc (a separator column alone): about 29 us of launch and memory
-// latency however little work they hold (measured at Final-13682, whose columns hold a dozen tiles), and past that the update's tile
-// products at what the chip sustains on them (64^3 fp64 multiply-adds each, about 20 TFLOP/s: 0.026 us); a backward step is one
+// dependent launches for one column of every arc (a separator column alone): the column launch (about 5 us: the diagonal tiles come
+// factored) and the update launch, whose longest path is the workgroup that also factors a diagonal tile of the next step (about 27 us
+// however little work the launch holds; measured at Final-13682, whose columns hold a dozen tiles), and past that the update's tile
+// products at what the memory system sustains on them (three tiles in, one out per product: 0.02 us each); a backward step is one
 // launch, about 6 us.
 inline double tile_order_cost(const std::vector<std::vector<int32_t>>& col_nodes, const std::vector<int32_t>& arc_start, const int n_arcs, const int nT) {
   auto pairs = [&](int k) { const double m = (double)col_nodes[k].size() + 1.0; return 0.5 * m * (m + 1.0); };
-  const double t_step = 29.0, t_pair = 0.026, t_back = 6.0;
+  const double t_step = 32.0, t_pair = 0.02, t_back = 6.0;
   double us = 0.0;
   int sep0 = 0;
   if (n_arcs > 1) {

@@ -26,16 +26,20 @@ namespace miba {
 //            the trailing blocks A_pq -= L_p L_q' on the matrix cores, operands straight from the factor in LDS;
 //   inverse  M = L^-1: the four diagonal blocks at once (lane = block, column: sixteen substitution steps), then the blocks at
 //            distance 1, 2, 3 from the diagonal, M_ab = -M_aa sum_c L_ac M_cb, two matrix-core stages each.
+// LOAD = false: the tile is in As already (k_tchol_update, which has just formed it).
+template <bool LOAD = true>
 __device__ __forceinline__ bool tchol_diag_wave(const double* __restrict__ A, const int lane, double* As /*[64][kLs]: the tile, then M = L^-1, row-major*/,
                                                 double* Lt /*[64][kLs]: Lt[k][r] = L[r][k]*/, double* Lr /*[64]: 1 / L[k][k]*/, double (*Sb)[256]) {
   const int r = lane & 15, g = lane >> 4;
+  if (LOAD) {
 #pragma unroll
-  for (int r0 = 0; r0 < kNB; r0 += 16) {
-    double v[16];
+    for (int r0 = 0; r0 < kNB; r0 += 16) {
+      double v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = A[(size_t)(r0 + i) * kNB + lane];
+      for (int i = 0; i < 16; ++i) v[i] = A[(size_t)(r0 + i) * kNB + lane];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) As[(r0 + i) * kLs + lane] = v[i];
+      for (int i = 0; i < 16; ++i) As[(r0 + i) * kLs + lane] = v[i];
+    }
   }
   bool bad = false;
 #pragma unroll
@@ -132,7 +136,9 @@ __device__ __forceinline__ bool tchol_diag_wave(const double* __restrict__ A, co
 // the column} turns its tile into X = A W = A L^-T.  Every workgroup factors and inverts the diagonal tile itself,
 // on its first wave, while the loads of its own tile are in flight: a launch that does it once and hands W over through memory
 // costs the column another launch ramp and two trips to memory (9 us where the product itself is 1.5).  The column's workgroup 0 leaves
-// W for the backward substitution.  Product on the fp64 matrix cores: wave = 16 rows, A fragment lane l = A[l & 15][4 kk + (l >> 4)],
+// W for the backward substitution.  A NEGATIVE diagonal slot says that W is in memory already: the update launch of the step before,
+// whose workgroup for (k, k) saw the tile's last update, has factored it there, beside the other updates of that launch instead of
+// at the head of this one (15 of a column launch's 21 us).  Product on the fp64 matrix cores: wave = 16 rows, A fragment lane l = A[l & 15][4 kk + (l >> 4)],
 // B[k][n] = W[k][16 nt + n] = M[16 nt + n][k] (zero for k >= 16 (nt + 1): M is lower block triangular), D: row (l >> 4) + 4 reg,
 // column l & 15.  In place: a wave reads all of its sixteen rows before it writes any of them, and nobody else touches them.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tchol_col(double* __restrict__ tiles, const int4* __restrict__ wg /*of this step*/,
@@ -149,7 +155,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   double af[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
-  if (wv == 0) {
+  if (e.x < 0) {
+    const double* Winv = Winv_all + (size_t)e.z * 4096;
+    double wv16[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wv16[q] = Winv[tid + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) As[(4 * q + wv) * kLs + l] = wv16[q];   // element tid + 256 q = row 4 q + wv, column l
+  } else if (wv == 0) {
     const bool bad = tchol_diag_wave(tiles + (size_t)e.x * 4096, l, As, Lt, Lr, Sb);
     if (e.w == 0) {
       if (bad && l == 0) *flag = 1;
@@ -178,38 +191,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // update lands in separator x separator tiles, or in the right-hand side of a separator column, the arc's PRIVATE tile: two arcs of
 // one step would otherwise add to the same tile at the same time; k_tchol_merge adds the private tiles to the matrix once all arcs
 // are done).
-__global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles, const int4* __restrict__ wg /*of this step*/) {
-  __shared__ double bt[kNB][kNB + 1];
+// e.w = c + 1 > 0: the destination is the diagonal tile of column c, which the NEXT step takes, and this is its last update: the
+// workgroup goes on to factor the tile (W_c = L_cc^-T into Winv_all, what k_tchol_col would otherwise do at the head of the next
+// launch) while the launch's other workgroups are still at their updates.  A negative operand slot: no update, the tile was complete
+// before this launch (no column of this step touches it): the workgroup only factors it.
+__global__ __launch_bounds__(256) void k_tchol_update(double* __restrict__ tiles, const int4* __restrict__ wg /*of this step*/,
+                                                      double* __restrict__ Winv_all, int* __restrict__ flag) {
+  __shared__ __align__(16) double Lt[kNB * kLs];   // first B', staged with a row stride of 65; the factor's L' afterwards
+  __shared__ __align__(16) double As[kNB * kLs];
+  __shared__ double Lr[kNB];
+  __shared__ double Sb[3][256];
+  double (*bt)[kNB + 1] = reinterpret_cast<double (*)[kNB + 1]>(Lt);
   const int4 e = wg[blockIdx.x];
-  const double* A = tiles + (size_t)e.x * 4096;
-  const double* B = tiles + (size_t)e.y * 4096;
   double* Dt = tiles + (size_t)e.z * 4096;
   const int tid = threadIdx.x;
   const int l = tid & 63, wv = tid >> 6;
   const int ar = l & 15, ak = l >> 4;
-  // both operands and the destination are requested together, before the first wait: one trip to memory.  (As a loop
-  // "load, store to LDS" the staging of B took sixteen trips, one per element and thread.)  The destination is negated as
-  // the accumulator's start.
-  double bv[16], af[16];
-  d4_t c[4];
+  if (e.x >= 0) {
+    const double* A = tiles + (size_t)e.x * 4096;
+    const double* B = tiles + (size_t)e.y * 4096;
+    // both operands and the destination are requested together, before the first wait: one trip to memory.  (As a loop
+    // "load, store to LDS" the staging of B took sixteen trips, one per element and thread.)  The destination is negated as
+    // the accumulator's start.
+    double bv[16], af[16];
+    d4_t c[4];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) bv[q] = B[tid + 256 * q];
+    for (int q = 0; q < 16; ++q) bv[q] = B[tid + 256 * q];
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
+    for (int kk = 0; kk < 16; ++kk) af[kk] = A[(size_t)(16 * wv + ar) * 64 + 4 * kk + ak];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) c[nt][reg] = -Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar];
-  __builtin_amdgcn_sched_barrier(0);
+      for (int reg = 0; reg < 4; ++reg) c[nt][reg] = -Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) bt[4 * q + wv][l] = bv[q];   // element tid + 256 q = row 4 q + wv, column l
-  __syncthreads();
+    for (int q = 0; q < 16; ++q) bt[4 * q + wv][l] = bv[q];   // element tid + 256 q = row 4 q + wv, column l
+    __syncthreads();
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) c[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bt[16 * nt + ar][4 * kk + ak], c[nt], 0, 0, 0);
+      for (int kk = 0; kk < 16; ++kk) c[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bt[16 * nt + ar][4 * kk + ak], c[nt], 0, 0, 0);
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] = -c[nt][reg];
+      for (int reg = 0; reg < 4; ++reg) Dt[(size_t)(16 * wv + ak + 4 * reg) * 64 + 16 * nt + ar] = -c[nt][reg];
+    }
+    if (e.w <= 0) return;   // (the same for the whole workgroup)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) As[(16 * wv + ak + 4 * reg) * kLs + 16 * nt + ar] = -c[nt][reg];
+  } else {
+    double tv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tv[q] = Dt[tid + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) As[(4 * q + wv) * kLs + l] = tv[q];   // element tid + 256 q = row 4 q + wv, column l
+  }
+  __syncthreads();   // the tile is in As, and nobody reads B' any more
+  if (wv == 0) {
+    const bool bad = tchol_diag_wave<false>(nullptr, l, As, Lt, Lr, Sb);
+    if (bad && l == 0) *flag = 1;
+    double* Winv = Winv_all + (size_t)(e.w - 1) * 4096;
+#pragma unroll 16
+    for (int cc = 0; cc < kNB; ++cc) Winv[cc * kNB + l] = (ak <= (cc >> 4)) ? As[cc * kLs + l] : 0.0;
   }
 }
 
