@@ -22,6 +22,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/miba.h"
@@ -226,10 +227,10 @@ struct miba_handle_s {
   std::vector<int32_t> sp_arc;
   int4* d_sp_wg = nullptr;
   std::vector<SpStep> sp_fwd, sp_bwd;   // backward steps use col0 / n_col only
-  size_t sp_merge_at = 0;               // forward steps before the merge of the private tiles
+  struct SpMerge { size_t at; int32_t ptr0, n; };   // before forward step `at`: merge destinations [ptr0, ptr0 + n) of the lists
+  std::vector<SpMerge> sp_merges;                   // (one per level of the order that left private tiles)
   int32_t *d_sp_merge_ptr = nullptr, *d_sp_merge_src = nullptr, *d_sp_merge_dst = nullptr;
   int64_t sp_n_priv = 0;           // private tiles (behind the right-hand-side tiles)
-  int32_t sp_n_merge = 0;          // destination tiles with private contributions
   int64_t sp_fill_tiles = 0;       // tiles below the diagonal after fill (reported)
   double *d_part_tile = nullptr, *d_part_small = nullptr, *d_part_pcg = nullptr;
   double *d_sum = nullptr, *d_max = nullptr;   // [S_COUNT] each
@@ -1326,10 +1327,7 @@ int sparse_symbolic(miba_handle h) {
   // of the separator's (about 8 tile rows per cut at Final-13682) and its denser columns.  The symbolic phase orders the graph for a
   // few arc counts and keeps the cheapest under tile_order_cost's model (every rank sees the same graph and takes the same
   // decision); MIBA_SPARSE_ARCS=1..64 fixes the number instead (tests, measurements).
-  int n_arcs = 1;
-  std::vector<int32_t> pos, grp, arc_start;
-  std::vector<std::vector<int32_t>> col_nodes;
-  int64_t n_off = 0;
+  TileOrder O;
   {
     std::vector<int> cand;
     if (const char* ea = getenv("MIBA_SPARSE_ARCS")) { const int v = atoi(ea); if (v >= 1 && v <= kMaxArcs) cand.push_back(v); }
@@ -1337,8 +1335,9 @@ int sparse_symbolic(miba_handle h) {
       for (int v : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64})
         if (v == 1 || nT >= 32 * v) cand.push_back(v);
     }
+    const bool nested = !(getenv("MIBA_SPARSE_NESTED") && getenv("MIBA_SPARSE_NESTED")[0] == '0');
     // (the candidates are ordered side by side on host threads: at 7,143 tile rows one ordering takes 40 ms)
-    struct Cand { std::vector<uint64_t> adj; std::vector<int32_t> pos, grp, arc; std::vector<std::vector<int32_t>> nodes; int64_t off = 0; int got = 0; bool ok = false; double cost = 0.0; };
+    struct Cand { std::vector<uint64_t> adj; TileOrder O; bool ok = false; double cost = 0.0; };
     std::vector<Cand> cs(cand.size());
     for (size_t i = 0; i < cand.size(); ++i) {
       if (i + 1 == cand.size()) cs[i].adj = std::move(adj);
@@ -1346,10 +1345,9 @@ int sparse_symbolic(miba_handle h) {
     }
     auto order_one = [&](size_t i) {
       Cand& c = cs[i];
-      c.got = cand[i];
       try {   // (a host thread: nothing may leave it)
-        c.ok = order_tile_graph(c.adj, nT, cand[i], max_tiles, h->cfg.log_level, c.got, c.grp, c.pos, c.nodes, c.arc, c.off);
-        if (c.ok) c.cost = tile_order_cost(c.nodes, c.arc, c.got, nT);
+        c.ok = order_tile_graph(c.adj, nT, cand[i], max_tiles, h->cfg.log_level, c.O, nested);
+        if (c.ok) c.cost = tile_order_cost(c.O);
       } catch (...) { c.ok = false; }
     };
     {
@@ -1363,19 +1361,30 @@ int sparse_symbolic(miba_handle h) {
     for (size_t i = 0; i < cand.size(); ++i) {
       Cand& c = cs[i];
       if (!c.ok) continue;
-      if (c.got != cand[i] && cand[i] != 1 && cand.size() > 1) continue;   // not dissected that finely: the plain order is a candidate of its own
-      if (h->cfg.log_level > 0 || getenv("MIBA_SPARSE_DEBUG"))
-        fprintf(stderr, "[miba] tile order with %d arc(s): %lld tiles below the diagonal, %d separator rows, modelled %.2f ms\n", c.got, (long long)c.off,
-                nT - c.arc[c.got], c.cost * 1e-3);
+      if (c.O.n_arcs != cand[i] && cand[i] != 1 && cand.size() > 1) continue;   // not dissected that finely: the plain order is a candidate of its own
+      if (h->cfg.log_level > 0 || getenv("MIBA_SPARSE_DEBUG")) {
+        int levels = 0;
+        for (int32_t l2 : c.O.group_level) levels = std::max(levels, (int)l2);
+        fprintf(stderr, "[miba] tile order with %d arc(s): %lld tiles below the diagonal, %d separator rows in %d set(s) on %d level(s), modelled %.2f ms\n",
+                c.O.n_arcs, (long long)c.O.n_off, nT - c.O.arc_start[c.O.n_arcs], (int)c.O.group_level.size() - c.O.n_arcs, levels, c.cost * 1e-3);
+      }
       if (!have || c.cost < best) {
-        have = true; best = c.cost; n_arcs = c.got; n_off = c.off;
-        pos.swap(c.pos); grp.swap(c.grp); arc_start.swap(c.arc); col_nodes.swap(c.nodes);
+        have = true; best = c.cost;
+        std::swap(O, c.O);
       }
     }
     if (!have) return MIBA_OK;   // does not fit: sparse_state stays -1
   }
+  const int n_arcs = O.n_arcs;
+  const std::vector<int32_t>&pos = O.pos, &grp = O.grp, &arc_start = O.arc_start;
+  const std::vector<std::vector<int32_t>>& col_nodes = O.col_nodes;
+  const int64_t n_off = O.n_off;
   const int sep0 = arc_start[n_arcs];          // first separator column (nT: none)
   const int nS = nT - sep0;
+  const int nG = (int)O.group_level.size();
+  std::vector<int32_t> group_of(nT), group_end(nT);
+  for (int g = 0; g < nG; ++g)
+    for (int k = O.group_start[g]; k < O.group_start[g + 1]; ++k) { group_of[k] = g; group_end[k] = O.group_start[g + 1]; }
 
   // slots: the diagonal tile of tile row p is slot p, the tiles below the diagonal follow column by column, then the
   // right-hand-side tile of every column
@@ -1403,71 +1412,85 @@ int sparse_symbolic(miba_handle h) {
     map[(size_t)nT * nT + k] = (int32_t)(n_mat + k);
   }
   col_ptr[nT] = (int64_t)col_rows.size();
-  // private tiles of the arcs: every (row, column) pair of an arc's column whose column lies in the separator
-  std::vector<int32_t> smap, merge_ptr, merge_src, merge_dst;
+  // private tiles of the groups: every (row, column) pair of a group's column whose column lies outside the group (in a set of a
+  // higher level: the groups of one level run side by side and may meet there).  They are added to the matrix, per destination in
+  // group order, in front of the first step of the next level (merge lists per level).
+  const bool split = nG > 1;
+  std::vector<std::unordered_map<int64_t, int32_t>> priv(nG);
+  std::vector<int32_t> merge_ptr, merge_src, merge_dst;
+  std::vector<std::array<int32_t, 3>> merge_seg;   // producing level, first destination, destinations
   int64_t n_priv = 0;
-  if (n_arcs > 1) {
-    smap.assign((size_t)n_arcs * (nS + 1) * nS, -1);
-    std::vector<std::pair<int32_t, int32_t>> contrib;   // (destination slot, private slot)
-    for (int a = 0; a < n_arcs; ++a) {
-      int32_t* sm = smap.data() + (size_t)a * (nS + 1) * nS;
-      for (int k = arc_start[a]; k < arc_start[a + 1]; ++k) {
-        const int32_t* rows = col_rows.data() + col_ptr[k] + 1;   // below the diagonal, ascending, the right-hand-side row (nT) last
-        const int m = (int)(col_ptr[k + 1] - col_ptr[k]) - 1;
-        int j0 = 0;
-        while (j0 < m && rows[j0] < sep0) ++j0;
-        for (int J = j0; J < m; ++J) {
-          if (rows[J] >= nT) break;
-          for (int I = J; I < m; ++I) {
-            int32_t& slot = sm[(size_t)(rows[I] - sep0) * nS + (rows[J] - sep0)];
-            if (slot < 0) {
-              slot = (int32_t)(n_mat + nT + n_priv++);
-              contrib.push_back({map[(size_t)rows[I] * nT + rows[J]], slot});
+  if (split) {
+    int max_level = 0;
+    for (int32_t l2 : O.group_level) max_level = std::max(max_level, (int)l2);
+    for (int l2 = 0; l2 < max_level; ++l2) {
+      std::vector<std::pair<int32_t, int32_t>> contrib;   // (destination slot, private slot)
+      for (int g = 0; g < nG; ++g) {
+        if (O.group_level[g] != l2) continue;
+        const int gend = O.group_start[g + 1];
+        for (int k = O.group_start[g]; k < gend; ++k) {
+          const int32_t* rows = col_rows.data() + col_ptr[k] + 1;   // below the diagonal, ascending, the right-hand-side row (nT) last
+          const int m = (int)(col_ptr[k + 1] - col_ptr[k]) - 1;
+          int j0 = 0;
+          while (j0 < m && rows[j0] < gend) ++j0;
+          for (int J = j0; J < m; ++J) {
+            if (rows[J] >= nT) break;
+            for (int I = J; I < m; ++I) {
+              const int64_t key = (int64_t)rows[I] * (nT + 1) + rows[J];
+              if (priv[g].find(key) == priv[g].end()) {
+                const int32_t slot = (int32_t)(n_mat + nT + n_priv++);
+                priv[g].emplace(key, slot);
+                contrib.push_back({map[(size_t)rows[I] * nT + rows[J]], slot});
+              }
             }
           }
         }
       }
+      if (contrib.empty()) continue;
+      std::stable_sort(contrib.begin(), contrib.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first < y.first; });
+      const int32_t d0 = (int32_t)merge_dst.size();
+      for (size_t i = 0; i < contrib.size(); ++i) {
+        if (i == 0 || contrib[i].first != contrib[i - 1].first) { merge_ptr.push_back((int32_t)merge_src.size()); merge_dst.push_back(contrib[i].first); }
+        merge_src.push_back(contrib[i].second);
+      }
+      merge_ptr.push_back((int32_t)merge_src.size());   // (every level's list has its own end)
+      merge_seg.push_back({l2, d0, (int32_t)merge_dst.size() - d0});
+      merge_dst.push_back(-1);                          // (keeps merge_ptr and merge_dst index for index)
     }
     if (2 * (int64_t)nT + n_off + n_priv > max_tiles) return MIBA_OK;   // does not fit
-    std::stable_sort(contrib.begin(), contrib.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first < y.first; });
-    for (size_t i = 0; i < contrib.size(); ++i) {
-      if (i == 0 || contrib[i].first != contrib[i - 1].first) { merge_ptr.push_back((int32_t)i); merge_dst.push_back(contrib[i].first); }
-      merge_src.push_back(contrib[i].second);
-    }
-    merge_ptr.push_back((int32_t)contrib.size());
   }
-  // The workgroup lists of every launch.  Forward: step s of the arcs' phase takes column arc_start[a] + s of every arc a that has one,
-  // then every separator column is a step of its own (one arc: every column).  Backward: the separator rows one by one from the last,
-  // then row arc_start[a + 1] - 1 - s of every arc (below the separator the rows of an arc touch only columns of the arc).
-  const bool split = n_arcs > 1;
+  // The workgroup lists of every launch.  Forward: the groups of a level in lock-step (tile_order_steps: step st of a level takes column
+  // group_start[g] + st of every group g of the level that has one), level after level.  Backward: the levels from the highest down,
+  // row group_start[g + 1] - 1 - st of every group (the rows of a group touch only columns of the group and of lower levels, and two
+  // groups of a level share no column).
   std::vector<miba_handle_s::SpStep> fwd, bwd;
   std::vector<std::vector<int32_t>> fwd_cols, bwd_rows;
-  size_t merge_at = 0;
+  std::vector<uint8_t> first_of_level;
+  tile_order_steps(O, fwd_cols, first_of_level);
+  std::vector<miba_handle_s::SpMerge> merges;
+  for (size_t st = 0; st < fwd_cols.size(); ++st) {
+    if (!first_of_level[st]) continue;
+    const int lv = O.group_level[group_of[fwd_cols[st][0]]];
+    // everything the levels below have left (a level without private tiles has no entry)
+    for (const auto& sg : merge_seg)
+      if (sg[0] < lv && (st == 0 || sg[0] >= O.group_level[group_of[fwd_cols[st - 1][0]]])) merges.push_back({st, sg[1], sg[2]});
+  }
   {
-    int longest = 0;
-    for (int a = 0; a < n_arcs && split; ++a) longest = std::max(longest, (int)(arc_start[a + 1] - arc_start[a]));
-    for (int st = 0; st < longest; ++st) {
-      std::vector<int32_t> ks;
-      for (int a = 0; a < n_arcs; ++a)
-        if (arc_start[a] + st < arc_start[a + 1]) ks.push_back(arc_start[a] + st);
-      fwd_cols.push_back(ks);
-    }
-    merge_at = fwd_cols.size();
-    for (int k = split ? sep0 : 0; k < nT; ++k) fwd_cols.push_back({k});
-    for (int k = nT - 1; k >= (split ? sep0 : 0); --k) bwd_rows.push_back({k});
-    for (int st = 0; st < longest; ++st) {
-      std::vector<int32_t> ks;
-      for (int a = 0; a < n_arcs; ++a)
-        if (arc_start[a + 1] - 1 - st >= arc_start[a]) ks.push_back(arc_start[a + 1] - 1 - st);
-      bwd_rows.push_back(ks);
+    int max_level = 0;
+    for (int32_t l2 : O.group_level) max_level = std::max(max_level, (int)l2);
+    for (int l2 = max_level; l2 >= 0; --l2) {
+      int longest = 0;
+      for (int g = 0; g < nG; ++g)
+        if (O.group_level[g] == l2) longest = std::max(longest, (int)(O.group_start[g + 1] - O.group_start[g]));
+      for (int st = 0; st < longest; ++st) {
+        std::vector<int32_t> ks;
+        for (int g = 0; g < nG; ++g)
+          if (O.group_level[g] == l2 && O.group_start[g + 1] - 1 - st >= O.group_start[g]) ks.push_back(O.group_start[g + 1] - 1 - st);
+        bwd_rows.push_back(ks);
+      }
     }
   }
-  auto chain_start = [&](int k) {   // first row of the chain of backward steps row k belongs to
-    if (!split || k >= sep0) return split ? sep0 : 0;
-    int a = 0;
-    while (k >= arc_start[a + 1]) ++a;
-    return (int)arc_start[a];
-  };
+  auto chain_start = [&](int k) { return (int)O.group_start[group_of[k]]; };   // first row of the chain of backward steps row k belongs to
   int64_t n_wg = 0;
   for (auto& ks : fwd_cols)
     for (int32_t k : ks) {
@@ -1495,29 +1518,24 @@ int sparse_symbolic(miba_handle h) {
     }
     S.n_col = (int32_t)(wg.size() - S.col0);
     S.upd0 = (int64_t)wg.size();
-    auto arc_map = [&](int32_t k) -> const int32_t* {
-      if (!(split && k < sep0)) return nullptr;
-      int a = 0;
-      while (k >= arc_start[a + 1]) ++a;
-      return smap.data() + (size_t)a * (nS + 1) * nS;
-    };
     // the updates that complete the next step's diagonal tiles first: they have the longest way to go
     for (int32_t k : ks) {
       const int64_t c0 = col_ptr[k];
       const int m = (int)(col_ptr[k + 1] - c0) - 1;
       const int32_t* rows = col_rows.data() + c0 + 1;
       const int32_t* slots = col_slots.data() + c0 + 1;
-      const bool to_private = arc_map(k) && k + 1 >= sep0;
+      const bool to_private = split && k + 1 >= group_end[k];
       if (ahead_on && m > 0 && rows[0] == k + 1 && k + 1 < nT && step_of[k + 1] == (int32_t)st + 1 && !to_private) {
         pre[k + 1] = 1;
         wg.push_back(int4{slots[0], slots[0], map[(size_t)(k + 1) * nT + (k + 1)], k + 2});
       }
     }
     // the other diagonal tiles of the next step were complete before this launch (no column of this step touches them): workgroups
-    // that only factor them.  Not the first separator column: the arcs' private tiles are merged into it behind this launch.
-    if (ahead_on && st + 1 < fwd_cols.size())
+    // that only factor them.  Not the first columns of a level: the private tiles of the levels below are merged into them behind
+    // this launch.
+    if (ahead_on && st + 1 < fwd_cols.size() && !first_of_level[st + 1])
       for (int32_t c : fwd_cols[st + 1])
-        if (!pre[c] && !(split && st + 1 == merge_at)) {
+        if (!pre[c]) {
           pre[c] = 1;
           wg.push_back(int4{-1, -1, c, c + 1});
         }
@@ -1526,12 +1544,17 @@ int sparse_symbolic(miba_handle h) {
       const int m = (int)(col_ptr[k + 1] - c0) - 1;
       const int32_t* rows = col_rows.data() + c0 + 1;
       const int32_t* slots = col_slots.data() + c0 + 1;
-      const int32_t* sm = arc_map(k);
+      const int gend = group_end[k];
+      const auto& pm = priv[group_of[k]];
       for (int J = 0; J < m; ++J) {
         if (rows[J] >= nT) break;
         for (int I = J; I < m; ++I) {
-          if (I == 0 && J == 0 && pre[k + 1] && rows[0] == k + 1) continue;   // listed above
-          const int32_t d = (sm && rows[J] >= sep0) ? sm[(size_t)(rows[I] - sep0) * nS + (rows[J] - sep0)] : map[(size_t)rows[I] * nT + rows[J]];
+          if (I == 0 && J == 0 && pre[k + 1] && rows[0] == k + 1 && k + 1 < gend) continue;   // listed above
+          int32_t d;
+          if (split && rows[J] >= gend) {
+            const auto it = pm.find((int64_t)rows[I] * (nT + 1) + rows[J]);
+            d = it == pm.end() ? -1 : it->second;
+          } else d = map[(size_t)rows[I] * nT + rows[J]];
           if (d < 0) return fail(h, MIBA_ERR_INVALID, "tile (%d, %d) is missing from the fill of column %d", rows[I], rows[J], k);
           wg.push_back(int4{slots[I], slots[J], d, 0});
         }
@@ -1581,13 +1604,12 @@ int sparse_symbolic(miba_handle h) {
   if ((rc = upload(h, h->d_sp_wg, wg.data(), wg.size()))) return rc;
   h->sp_fwd.swap(fwd);
   h->sp_bwd.swap(bwd);
-  h->sp_merge_at = merge_at;
+  h->sp_merges.swap(merges);
   h->sp_nT = nT;
   h->sp_n_mat = n_mat;
   h->sp_n_arcs = n_arcs;
   h->sp_arc.assign(arc_start.begin(), arc_start.end());
   h->sp_n_priv = n_priv;
-  h->sp_n_merge = (int32_t)merge_dst.size();
   h->sp_fill_tiles = n_off;
   if (split) {
     if ((rc = upload(h, h->d_sp_merge_ptr, merge_ptr.data(), merge_ptr.size()))) return rc;
@@ -1598,8 +1620,9 @@ int sparse_symbolic(miba_handle h) {
   {
     int64_t n_pairs = 0;
     for (const miba_handle_s::SpStep& S : h->sp_fwd) n_pairs += S.n_upd;
-    fprintf(stderr, "[miba] tile factorisation: %d tile rows, %lld tiles below the diagonal after fill, %d arc(s), %d separator rows, %lld private tiles, "
-            "%zu forward steps, %lld tile products\n", nT, (long long)n_off, n_arcs, nS, (long long)n_priv, h->sp_fwd.size(), (long long)n_pairs);
+    fprintf(stderr, "[miba] tile factorisation: %d tile rows, %lld tiles below the diagonal after fill, %d arc(s), %d separator rows in %d set(s), "
+            "%lld private tiles, %zu forward steps, %lld tile products\n", nT, (long long)n_off, n_arcs, nS, nG - n_arcs, (long long)n_priv, h->sp_fwd.size(),
+            (long long)n_pairs);
   }
   if (!h->dense_plan_tried && (rc = dense_plan(h))) return rc;
   h->sparse_state = 1;
@@ -1621,9 +1644,10 @@ int sparse_solve(miba_handle h, int* status) {
   // one stream, one chain of launches: a forward step is the column launch and the update launch of all its columns
   if (h->sp_n_priv) HIPCHK(h, hipMemsetAsync(T + (size_t)(n_mat + nT) * 4096, 0, (size_t)h->sp_n_priv * 4096 * sizeof(double), h->st));
   for (size_t i = 0; i < h->sp_fwd.size(); ++i) {
-    if (i == h->sp_merge_at && h->sp_n_merge)
-      hipLaunchKernelGGL(k_tchol_merge, dim3(h->sp_n_merge), dim3(256), 0, h->st, T, (const int32_t*)h->d_sp_merge_ptr, (const int32_t*)h->d_sp_merge_src,
-                         (const int32_t*)h->d_sp_merge_dst);
+    for (const miba_handle_s::SpMerge& M : h->sp_merges)
+      if (M.at == i && M.n > 0)
+        hipLaunchKernelGGL(k_tchol_merge, dim3(M.n), dim3(256), 0, h->st, T, (const int32_t*)(h->d_sp_merge_ptr + M.ptr0), (const int32_t*)h->d_sp_merge_src,
+                           (const int32_t*)(h->d_sp_merge_dst + M.ptr0));
     const miba_handle_s::SpStep& S = h->sp_fwd[i];
     hipLaunchKernelGGL(k_tchol_col, dim3(S.n_col), dim3(256), 0, h->st, T, (const int4*)(h->d_sp_wg + S.col0), h->d_sp_Ldiag, (int*)h->d_dflag);
     if (S.n_upd) hipLaunchKernelGGL(k_tchol_update, dim3(S.n_upd), dim3(256), 0, h->st, T, (const int4*)(h->d_sp_wg + S.upd0), h->d_sp_Ldiag, (int*)h->d_dflag);
@@ -2152,7 +2176,8 @@ int miba_plan_product_stats(const miba_problem* p, double* out10) {
 }
 
 int miba_plan_tile_order(int32_t n_rows, const int32_t* eu, const int32_t* ev, int64_t n_edges, int32_t n_arcs, int32_t* pos_out,
-                         int32_t* arc_start_out, int32_t* n_arcs_out, int64_t* fill_tiles, double* cost_us) {
+                         int32_t* arc_start_out, int32_t* n_arcs_out, int64_t* fill_tiles, double* cost_us, int32_t nested, int32_t* group_start,
+                         int32_t* group_level, int32_t* n_groups) {
   if (n_rows < 1 || n_rows > 32768 || n_edges < 0 || (n_edges && (!eu || !ev)) || !pos_out || !arc_start_out || n_arcs < 1 || n_arcs > kMaxArcs)
     return fail(nullptr, MIBA_ERR_INVALID, "bad tile graph");
   const size_t nW = ((size_t)n_rows + 63) / 64;
@@ -2164,17 +2189,21 @@ int miba_plan_tile_order(int32_t n_rows, const int32_t* eu, const int32_t* ev, i
     adj[(size_t)u * nW + (v >> 6)] |= (uint64_t)1 << (v & 63);
     adj[(size_t)v * nW + (u >> 6)] |= (uint64_t)1 << (u & 63);
   }
-  int na = n_arcs;
-  std::vector<int32_t> grp, pos, arc_start;
-  std::vector<std::vector<int32_t>> col_nodes;
-  int64_t n_off = 0;
-  if (!order_tile_graph(adj, n_rows, n_arcs, (int64_t)1 << 40, 0, na, grp, pos, col_nodes, arc_start, n_off))
+  TileOrder O;
+  if (!order_tile_graph(adj, n_rows, n_arcs, (int64_t)1 << 40, 0, O, nested != 0))
     return fail(nullptr, MIBA_ERR_LIMIT, "tile graph too large");
-  for (int32_t v = 0; v < n_rows; ++v) pos_out[v] = pos[v];
-  for (int a = 0; a <= n_arcs; ++a) arc_start_out[a] = arc_start[std::min(a, na)];
+  const int na = O.n_arcs;
+  for (int32_t v = 0; v < n_rows; ++v) pos_out[v] = O.pos[v];
+  for (int a = 0; a <= n_arcs; ++a) arc_start_out[a] = O.arc_start[std::min(a, na)];
   if (n_arcs_out) *n_arcs_out = na;
-  if (fill_tiles) *fill_tiles = n_off;
-  if (cost_us) *cost_us = tile_order_cost(col_nodes, arc_start, na, n_rows);
+  if (fill_tiles) *fill_tiles = O.n_off;
+  if (cost_us) *cost_us = tile_order_cost(O);
+  const int nG = (int)O.group_level.size();
+  if (n_groups) *n_groups = nG;
+  if (group_start && group_level) {
+    for (int g = 0; g < nG && g < 2 * n_arcs; ++g) { group_start[g] = O.group_start[g]; group_level[g] = O.group_level[g]; }
+    group_start[std::min(nG, 2 * n_arcs)] = n_rows;
+  }
   return MIBA_OK;
 }
 

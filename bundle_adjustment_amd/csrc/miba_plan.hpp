@@ -19,6 +19,7 @@
 #include <numeric>
 #include <chrono>
 #include <cstdio>
+#include <array>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -558,62 +559,118 @@ inline int build_plan(Plan& P, int32_t n_cam, int32_t n_pt, int64_t n_obs, const
 // ---- elimination order of the tile graph of the exact solve (sparse_symbolic in miba.hip; host only) ----------------------------
 // adj: nT rows of nW = ceil(nT / 64) words, bit u of row v set when tile rows u and v share an entry (no diagonal); destroyed.
 // Out: the order (grp[k] = tile row eliminated at step k, pos = its inverse), per step the rows below the diagonal after fill
-// (col_nodes, as tile rows), their total n_off, the number of arcs the order was dissected into and the first step of every arc
-// (arc_start[n_arcs] = first separator step, nT when there is none).  false: more than max_tiles tiles.
-constexpr int kMaxArcs = 64;   // arcs of the dissected order (part[] below is int8_t)
+// (col_nodes, as tile rows), their total n_off, the number of arcs the order was dissected into, the first step of every arc
+// (arc_start[n_arcs] = first separator step, nT when there is none), and the GROUPS of the order: group g holds the steps
+// [group_start[g], group_start[g + 1]) and has level group_level[g]; the arcs are the groups of level 0, the separator sets follow
+// by level.  Groups of one level share no tile and every column of a group holds rows of its own group and of higher levels only, so
+// the groups of a level are factored side by side.  false: more than max_tiles tiles.
+constexpr int kMaxArcs = 64;   // arcs of the dissected order
+struct TileOrder {
+  int n_arcs = 1;
+  std::vector<int32_t> grp, pos, arc_start, group_start, group_level;
+  std::vector<std::vector<int32_t>> col_nodes;
+  int64_t n_off = 0;
+};
 inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int n_arcs_wanted, const int64_t max_tiles, const int log_level,
-                             int& n_arcs_out, std::vector<int32_t>& grp_out, std::vector<int32_t>& pos_out,
-                             std::vector<std::vector<int32_t>>& col_nodes_out, std::vector<int32_t>& arc_start_out, int64_t& n_off_out) {
+                             TileOrder& out, const bool nested = true) {
   const size_t nW = ((size_t)nT + 63) / 64;
   int n_arcs = n_arcs_wanted;
   // Dissection of the tile graph into arcs that can be factored side by side (the elimination order of a band is a chain: at
-  // Final-13682 1,955 tile columns of 29 us each).  The tile rows are cut by index into n_arcs equal ranges; an edge between two
-  // ranges puts its higher end into the separator (rows ascending: a valid cover of the crossing edges; on a band these are the
-  // first rows behind every cut, on a ring also the last rows, which close it).  Interiors of different arcs then share no edge, and
-  // eliminating an interior row creates fill only inside its arc and towards the separator: the arcs' columns are independent of
-  // each other, the separator rows come last.  Only camera numberings with locality (what BAL files and the stand-in have) dissect
-  // this way; if the separator takes more than a third of the rows the order stays plain minimum degree, one chain.
+  // Final-13682 1,955 tile columns, each waiting for the one before it).  The tile rows are cut by index into n_arcs equal ranges; an
+  // edge between two ranges puts its higher end into a separator (rows ascending: a valid cover of the crossing edges; on a band these
+  // are the first rows behind every cut, on a ring also the last rows, which close it).  Interiors of different arcs then share no
+  // edge, and eliminating an interior row creates fill only inside its arc and towards the separators.
+  // NESTED: the cuts form a binary tree over the arcs (the root cut halves the range, its children halve the halves, ...).  An edge
+  // between arcs a < b crosses the cut that is their lowest common ancestor; its higher end joins THAT cut's separator set unless the
+  // lower end already sits in a set of that height or above (which covers the edge).  A set's level is the height of its cut (1 for a
+  // cut between two arcs).  Two sets of one height lie in disjoint subtrees, and every edge that leaves a subtree has its higher end in
+  // a set above the subtree's root: after the levels below are eliminated, sets of one level share no edge, so the sets of a level are
+  // factored side by side like the arcs, and the separator's chain is (levels) x (rows of a set) steps instead of all its rows.
+  // Not nested: every separator row in ONE set of level 1 (the first form of round 3).
+  // Only camera numberings with locality (what BAL files and the stand-in have) dissect this way; if the separators take more than a
+  // third of the rows the order stays plain minimum degree, one chain.
   if (nT < 8 * n_arcs) n_arcs = 1;
-  std::vector<int8_t> part(nT, 0);   // arc of a tile row; n_arcs = separator
+  if (n_arcs > kMaxArcs) n_arcs = kMaxArcs;
+  std::vector<int32_t> lvl(nT, 0), gid(nT, 0);   // level and group of a tile row: arcs are groups 0 .. n_arcs - 1 (level 0), cut c is group n_arcs + c
+  std::vector<int32_t> cut_height;               // per cut
+  std::vector<uint64_t> adj_keep;
   if (n_arcs > 1) {
+    if (nested) adj_keep = adj;   // (for the fall-back below)
+    // cuts of the binary tree, and the cut that separates arcs a < b
+    std::vector<int32_t> lca((size_t)n_arcs * n_arcs, -1);
+    struct Node { int lo, hi; };
+    std::vector<Node> stack{{0, n_arcs}};
+    std::vector<std::array<int, 3>> cuts;   // lo, mid, hi
+    while (!stack.empty()) {
+      const Node nd = stack.back(); stack.pop_back();
+      if (nd.hi - nd.lo < 2) continue;
+      const int mid = nd.lo + (nd.hi - nd.lo + 1) / 2;
+      cuts.push_back({nd.lo, mid, nd.hi});
+      stack.push_back({nd.lo, mid}); stack.push_back({mid, nd.hi});
+    }
+    cut_height.assign(cuts.size(), 1);
+    // height = 1 + the larger height of the two halves' own cuts (cuts of [lo, hi) with fewer than two arcs do not exist: height 0)
+    auto height_of = [&](auto&& self, int lo, int hi) -> int {
+      if (hi - lo < 2) return 0;
+      const int mid = lo + (hi - lo + 1) / 2;
+      return 1 + std::max(self(self, lo, mid), self(self, mid, hi));
+    };
+    for (size_t c = 0; c < cuts.size(); ++c) {
+      cut_height[c] = nested ? height_of(height_of, cuts[c][0], cuts[c][2]) : 1;
+      for (int a2 = cuts[c][0]; a2 < cuts[c][1]; ++a2)
+        for (int b2 = cuts[c][1]; b2 < cuts[c][2]; ++b2) lca[(size_t)a2 * n_arcs + b2] = (int32_t)c;
+    }
     auto arc_of = [&](int v) { return (int)std::min<int64_t>(n_arcs - 1, (int64_t)v * n_arcs / nT); };
     int n_sep = 0;
     for (int v = 0; v < nT; ++v) {
       const int av = arc_of(v);
       const uint64_t* row = &adj[(size_t)v * nW];
-      bool mark = false, past = false;
-      for (size_t w = 0; w < nW && !mark && !past; ++w)
+      int best = 0, best_cut = -1;
+      bool past = false;
+      for (size_t w = 0; w < nW && !past; ++w)
         for (uint64_t m = row[w]; m; m &= m - 1) {
           const int u = (int)(64 * w + __builtin_ctzll(m));
           if (u >= v) { past = true; break; }
-          if (part[u] != n_arcs && arc_of(u) != av) { mark = true; break; }
+          const int au = arc_of(u);
+          if (au == av) continue;
+          const int c = lca[(size_t)std::min(au, av) * n_arcs + std::max(au, av)];
+          const int hgt = cut_height[c];
+          if (lvl[u] >= hgt) continue;   // the lower end covers this edge
+          if (hgt > best) { best = hgt; best_cut = c; }
         }
-      part[v] = (int8_t)(mark ? n_arcs : av);
-      n_sep += mark;
+      lvl[v] = best;
+      gid[v] = best ? n_arcs + (nested ? best_cut : 0) : av;
+      n_sep += best > 0;
     }
     if (3 * n_sep > nT) {
-      if (log_level > 0) fprintf(stderr, "[miba] tile graph: %d of %d tile rows in the separator of %d arcs: not dissected\n", n_sep, nT, n_arcs);
+      if (log_level > 0) fprintf(stderr, "[miba] tile graph: %d of %d tile rows in the separators of %d arcs: not dissected\n", n_sep, nT, n_arcs);
       n_arcs = 1;
-      std::fill(part.begin(), part.end(), 0);
+      std::fill(lvl.begin(), lvl.end(), 0);
+      std::fill(gid.begin(), gid.end(), 0);
+      std::vector<uint64_t>().swap(adj_keep);
     }
   }
-  int interior_left = 0;
-  for (int v = 0; v < nT; ++v) interior_left += part[v] != n_arcs || n_arcs == 1;
+  int max_level = 0;
+  for (int v = 0; v < nT; ++v) max_level = std::max(max_level, (int)lvl[v]);
+  std::vector<int32_t> left(max_level + 1, 0);
+  for (int v = 0; v < nT; ++v) ++left[lvl[v]];
 
-  // minimum degree on the tile graph (ties: the lowest tile row, which keeps a banded problem banded); separator rows only after
-  // every interior row
+  // minimum degree on the tile graph (ties: the lowest tile row, which keeps a banded problem banded), level by level
   auto popcnt_row = [&](int v) { int c = 0; for (size_t w = 0; w < nW; ++w) c += __builtin_popcountll(adj[(size_t)v * nW + w]); return c; };
   std::vector<int32_t> deg(nT), pos(nT, -1), grp(nT);
   for (int v = 0; v < nT; ++v) deg[v] = popcnt_row(v);
   std::vector<std::vector<int32_t>> col_nodes(nT);
   int64_t n_off = 0;
+  int cur = 0;
+  bool ok_groups = true;
   for (int k = 0; k < nT; ++k) {
+    while (left[cur] == 0) ++cur;
     int v = -1;
     for (int u = 0; u < nT; ++u)
-      if (pos[u] < 0 && (interior_left == 0 || n_arcs == 1 || part[u] != n_arcs) && (v < 0 || deg[u] < deg[v])) v = u;
+      if (pos[u] < 0 && lvl[u] == cur && (v < 0 || deg[u] < deg[v])) v = u;
     pos[v] = k;
     grp[k] = v;
-    if (interior_left > 0) --interior_left;
+    --left[cur];
     std::vector<int32_t>& nb = col_nodes[k];
     const uint64_t* av = &adj[(size_t)v * nW];
     for (size_t w = 0; w < nW; ++w)
@@ -621,6 +678,7 @@ inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int
     n_off += (int64_t)nb.size();
     if (2 * (int64_t)nT + n_off > max_tiles) return false;   // does not fit
     for (int32_t u : nb) {
+      if (!(gid[u] == gid[v] || lvl[u] > lvl[v])) ok_groups = false;   // (cannot happen by construction: checked, not assumed)
       uint64_t* au = &adj[(size_t)u * nW];
       for (size_t w = 0; w < nW; ++w) au[w] |= av[w];
       au[v >> 6] &= ~((uint64_t)1 << (v & 63));
@@ -629,55 +687,94 @@ inline bool order_tile_graph(std::vector<uint64_t>& adj, const int nT, const int
     }
   }
   std::vector<uint64_t>().swap(adj);
-  // the steps of one arc side by side in the order (a stable regrouping: rows of different arcs do not interact, so the fill is
-  // the same), the separator's steps last
-  std::vector<int32_t> arc_start(n_arcs + 1, nT);
+  if (!ok_groups) {
+    if (log_level > 0) fprintf(stderr, "[miba] tile graph: the groups of %d arcs are not independent: %s\n", n_arcs, nested ? "one separator set" : "not dissected");
+    if (nested && !adj_keep.empty()) return order_tile_graph(adj_keep, nT, n_arcs_wanted, max_tiles, log_level, out, false);
+    return false;
+  }
+  // the steps of one group side by side in the order (a stable regrouping: the groups of a level do not interact, so the fill is the
+  // same): the arcs, then the separator sets level by level
+  std::vector<int32_t> arc_start(n_arcs + 1, nT), group_start, group_level;
   if (n_arcs > 1) {
+    const int n_gid = n_arcs + (int)std::max<size_t>(1, cut_height.size());
+    std::vector<int32_t> g_level(n_gid, -1);
+    for (int v = 0; v < nT; ++v) g_level[gid[v]] = lvl[v];
+    for (int a2 = 0; a2 < n_arcs; ++a2) g_level[a2] = 0;   // (an arc without interior rows keeps its entry in arc_start)
+    std::vector<int32_t> g_order;
+    for (int l2 = 0; l2 <= max_level; ++l2)
+      for (int g = 0; g < n_gid; ++g)
+        if (g_level[g] == l2) g_order.push_back(g);
+    std::vector<std::vector<int32_t>> steps_of(n_gid);
+    for (int k = 0; k < nT; ++k) steps_of[gid[grp[k]]].push_back(k);
     std::vector<int32_t> grp2(nT);
     std::vector<std::vector<int32_t>> nodes2(nT);
     int at = 0;
-    for (int a = 0; a <= n_arcs; ++a) {
-      arc_start[a] = at;
-      for (int k = 0; k < nT; ++k)
-        if (part[grp[k]] == a) { grp2[at] = grp[k]; nodes2[at].swap(col_nodes[k]); ++at; }
+    for (int g : g_order) {
+      if (g < n_arcs) arc_start[g] = at;
+      else if (arc_start[n_arcs] == nT && at < nT) arc_start[n_arcs] = at;
+      if (!steps_of[g].empty() || g < n_arcs) { group_start.push_back(at); group_level.push_back(g_level[g]); }
+      for (int32_t k : steps_of[g]) { grp2[at] = grp[k]; nodes2[at].swap(col_nodes[k]); ++at; }
     }
+    group_start.push_back(nT);
+    if (arc_start[n_arcs] == nT && max_level == 0) arc_start[n_arcs] = nT;
     grp.swap(grp2);
     col_nodes.swap(nodes2);
     for (int k = 0; k < nT; ++k) pos[grp[k]] = k;
-  } else arc_start[0] = 0;
-  n_arcs_out = n_arcs;
-  grp_out.swap(grp);
-  pos_out.swap(pos);
-  col_nodes_out.swap(col_nodes);
-  arc_start_out.swap(arc_start);
-  n_off_out = n_off;
+  } else {
+    arc_start[0] = 0;
+    group_start = {0, nT};
+    group_level = {0};
+  }
+  out.n_arcs = n_arcs;
+  out.grp.swap(grp);
+  out.pos.swap(pos);
+  out.col_nodes.swap(col_nodes);
+  out.arc_start.swap(arc_start);
+  out.group_start.swap(group_start);
+  out.group_level.swap(group_level);
+  out.n_off = n_off;
   return true;
 }
 
-
-// What the numeric phase pays for an order, in microseconds (sparse_symbolic chooses the number of arcs by it).  A forward step is two
-// dependent launches for one column of every arc (a separator column alone): the column launch (about 5 us: the diagonal tiles come
-// factored) and the update launch, whose longest path is the workgroup that also factors a diagonal tile of the next step (about 27 us
-// however little work the launch holds; measured at Final-13682, whose columns hold a dozen tiles), and past that the update's tile
-// products at what the memory system sustains on them (three tiles in, one out per product: 0.02 us each); a backward step is one
-// launch, about 6 us.
-inline double tile_order_cost(const std::vector<std::vector<int32_t>>& col_nodes, const std::vector<int32_t>& arc_start, const int n_arcs, const int nT) {
-  auto pairs = [&](int k) { const double m = (double)col_nodes[k].size() + 1.0; return 0.5 * m * (m + 1.0); };
-  const double t_step = 32.0, t_pair = 0.02, t_back = 6.0;
-  double us = 0.0;
-  int sep0 = 0;
-  if (n_arcs > 1) {
-    sep0 = arc_start[n_arcs];
+// The forward steps of an order: the groups of a level in lock-step (step st of the level takes column group_start[g] + st of every
+// group g of the level that has one), level after level.  first_of_level[i]: step i is the first of a level above 0 (the private
+// tiles of the levels below are merged in front of it).
+inline void tile_order_steps(const TileOrder& O, std::vector<std::vector<int32_t>>& steps, std::vector<uint8_t>& first_of_level) {
+  steps.clear(); first_of_level.clear();
+  const int nG = (int)O.group_level.size();
+  int max_level = 0;
+  for (int g = 0; g < nG; ++g) max_level = std::max(max_level, (int)O.group_level[g]);
+  for (int l2 = 0; l2 <= max_level; ++l2) {
     int longest = 0;
-    for (int a = 0; a < n_arcs; ++a) longest = std::max(longest, (int)(arc_start[a + 1] - arc_start[a]));
+    for (int g = 0; g < nG; ++g)
+      if (O.group_level[g] == l2) longest = std::max(longest, (int)(O.group_start[g + 1] - O.group_start[g]));
     for (int st = 0; st < longest; ++st) {
-      double w = 0.0;
-      for (int a = 0; a < n_arcs; ++a)
-        if (arc_start[a] + st < arc_start[a + 1]) w += pairs(arc_start[a] + st);
-      us += std::max(t_step, t_pair * w) + t_back;
+      std::vector<int32_t> ks;
+      for (int g = 0; g < nG; ++g)
+        if (O.group_level[g] == l2 && O.group_start[g] + st < O.group_start[g + 1]) ks.push_back(O.group_start[g] + st);
+      steps.push_back(ks);
+      first_of_level.push_back(st == 0 && l2 > 0);
     }
   }
-  for (int k = sep0; k < nT; ++k) us += std::max(t_step, t_pair * pairs(k)) + t_back;
+}
+
+// What the numeric phase pays for an order, in microseconds (sparse_symbolic chooses the number of arcs by it).  A forward step is two
+// dependent launches for one column of every group of a level: the column launch (about 5 us: the diagonal tiles come factored) and
+// the update launch, whose longest path is the workgroup that also factors a diagonal tile of the next step (about 27 us however little
+// work the launch holds; measured at Final-13682, whose columns hold a dozen tiles), and past that the update's tile products at what
+// the memory system sustains on them (three tiles in, one out per product: 0.02 us each); a backward step is one launch, about 6 us.
+inline double tile_order_cost(const TileOrder& O) {
+  auto pairs = [&](int k) { const double m = (double)O.col_nodes[k].size() + 1.0; return 0.5 * m * (m + 1.0); };
+  const double t_step = 32.0, t_pair = 0.02, t_back = 6.0;
+  std::vector<std::vector<int32_t>> steps;
+  std::vector<uint8_t> first;
+  tile_order_steps(O, steps, first);
+  double us = 0.0;
+  for (const auto& ks : steps) {
+    double w = 0.0;
+    for (int32_t k : ks) w += pairs(k);
+    us += std::max(t_step, t_pair * w) + t_back;
+  }
   return us;
 }
 

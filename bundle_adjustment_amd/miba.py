@@ -179,18 +179,21 @@ def plan_point_owner(n_cam, n_pt, obs_cam, obs_pt, obs_xy, world_size):
     return owner
 
 
-def plan_tile_order(n_rows, edges_u, edges_v, n_arcs):
+def plan_tile_order(n_rows, edges_u, edges_v, n_arcs, nested=True):
     """Host-only: elimination order of a tile graph as the exact solve's symbolic phase computes it (miba_plan_tile_order)."""
     eu = np.ascontiguousarray(edges_u, dtype=np.int32)
     ev = np.ascontiguousarray(edges_v, dtype=np.int32)
     pos = np.zeros(n_rows, dtype=np.int32)
     arc = np.zeros(n_arcs + 1, dtype=np.int32)
-    na, fill, cost = C.c_int32(0), C.c_int64(0), C.c_double(0.0)
+    gs, gl = np.zeros(2 * n_arcs + 1, dtype=np.int32), np.zeros(2 * n_arcs, dtype=np.int32)
+    na, fill, cost, ng = C.c_int32(0), C.c_int64(0), C.c_double(0.0), C.c_int32(0)
     rc = lib().miba_plan_tile_order(C.c_int32(n_rows), _ip(eu), _ip(ev), C.c_int64(eu.size), C.c_int32(n_arcs), _ip(pos), _ip(arc),
-                                    C.byref(na), C.byref(fill), C.byref(cost))
+                                    C.byref(na), C.byref(fill), C.byref(cost), C.c_int32(1 if nested else 0), _ip(gs), _ip(gl), C.byref(ng))
     if rc != 0:
         raise MibaError("miba_plan_tile_order rc=%d: %s" % (rc, (lib().miba_last_error(None) or b"").decode()))
-    return dict(pos=pos, arc_start=[int(a) for a in arc[:na.value + 1]], n_arcs=na.value, fill_tiles=fill.value, cost_us=cost.value)
+    n_g = min(ng.value, 2 * n_arcs)
+    return dict(pos=pos, arc_start=[int(a) for a in arc[:na.value + 1]], n_arcs=na.value, fill_tiles=fill.value, cost_us=cost.value,
+                group_start=[int(a) for a in gs[:n_g + 1]], group_level=[int(a) for a in gl[:n_g]])
 
 
 def plan_product_stats(n_cam, n_pt, obs_cam, obs_pt, obs_xy):

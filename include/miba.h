@@ -326,11 +326,14 @@ int miba_plan_point_owner(const miba_problem* p, int32_t world_size, int32_t* ow
  * order_tile_graph: index cuts into n_arcs arcs, the higher end of every crossing edge into the separator, minimum degree inside,
  * separator last); no counterpart in the reference (Ceres' ordering code plays this role behind ceres::Solve).  The graph has
  * n_rows vertices (tile rows) and n_edges undirected edges (eu[i], ev[i]); n_arcs is 1..64.  Outputs: pos[n_rows] = elimination step
- * of every row, arc_start[n_arcs + 1] = first step of every arc and of the separator (entries past *n_arcs_out repeat the separator's
- * start), the number of arcs the order ended up with (1: not dissected), the number of tiles below the diagonal after fill, and
- * (cost_us, may be null) the modelled time of the numeric phase by which the symbolic phase chooses the number of arcs.  Test hook. */
+ * of every row, arc_start[n_arcs + 1] = first step of every arc and of the separator rows (entries past *n_arcs_out repeat the
+ * separator's start), the number of arcs the order ended up with (1: not dissected), the number of tiles below the diagonal after
+ * fill, (cost_us, may be null) the modelled time of the numeric phase by which the symbolic phase chooses the number of arcs, and
+ * (group_start[2 n_arcs + 1], group_level[2 n_arcs], n_groups; may be null) the groups of the order: the arcs (level 0), then the
+ * separator sets by level; the groups of a level are factored side by side.  nested = 0: one separator set (level 1).  Test hook. */
 int miba_plan_tile_order(int32_t n_rows, const int32_t* eu, const int32_t* ev, int64_t n_edges, int32_t n_arcs,
-                         int32_t* pos, int32_t* arc_start, int32_t* n_arcs_out, int64_t* fill_tiles, double* cost_us);
+                         int32_t* pos, int32_t* arc_start, int32_t* n_arcs_out, int64_t* fill_tiles, double* cost_us,
+                         int32_t nested, int32_t* group_start, int32_t* group_level, int32_t* n_groups);
 
 /* Host-only diagnostic of the product kernel's layout (camera-major sub-tiles, csrc/miba_mf2.hpp) for one shard; no counterpart
  * in the reference (Ceres keeps its block-sparse Jacobian in one layout). out10 = { layout is a permutation of the non-giant

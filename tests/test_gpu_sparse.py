@@ -80,12 +80,13 @@ def test_tiles_equal_dense(shape, assembly):
 
 
 @pytest.mark.parametrize("shape,arcs", [("ring-300", 2), ("ring-300", 3), ("ring-1500", 4), ("scrambled-300", 3), ("ring-1500", 1), ("ring-1500", 8),
-                                        ("ring-2000", 0)])
+                                        ("ring-1500", 16), ("ring-2000", 0)])
 def test_dissected_order_equals_dense(shape, arcs):
     """the tile rows cut into arcs that are factored side by side (every launch takes one column of every arc), their separator updates
     collected in private tiles and merged (csrc/miba.hip: sparse_symbolic, sparse_solve): the same step as the dense factorisation.
     A scrambled camera numbering has no small separator: the order falls back to plain minimum degree (and must still be right).
-    arcs = 0: the number of arcs the symbolic phase chooses by its cost model."""
+    From four arcs up the separator rows form nested sets (one per cut of a binary tree over the arcs), factored side by side level by
+    level with private tiles and a merge per level.  arcs = 0: the number of arcs the symbolic phase chooses by its cost model."""
     kind, n_cam = shape.split("-")
     n_cam = int(n_cam)
     pr = synth.make_problem(n_cam, 40 * n_cam, 170 * n_cam, seed=n_cam)

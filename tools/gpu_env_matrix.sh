@@ -29,6 +29,8 @@ run MIBA_TAIL_SPLIT=1 || exit 1
 run MIBA_SPARSE_ARCS=1 || exit 1
 run MIBA_SPARSE_ARCS=2 || exit 1
 run MIBA_SPARSE_ARCS=16 || exit 1
+run MIBA_SPARSE_NESTED=0 || exit 1
+run MIBA_SPARSE_AHEAD=0 || exit 1
 run MIBA_XCD_REMAP=0 || exit 1
 run MIBA_ALLREDUCE=peer MIBA_TAIL_NO_FUSE=1 || exit 1
 # the tests of the exact solve and the multi-rank runs that use it are left out when it is switched off
