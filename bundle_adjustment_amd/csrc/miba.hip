@@ -217,10 +217,10 @@ struct miba_handle_s {
   int64_t sp_n_mat = 0;            // tiles of the matrix; the right-hand-side tiles follow them
   double *d_sp_tiles = nullptr, *d_sp_Ldiag = nullptr, *d_sp_y = nullptr, *d_sp_x = nullptr;
   int32_t *d_sp_map = nullptr, *d_sp_pos = nullptr, *d_sp_grp = nullptr;
-  // dissection of the tile graph (sparse_symbolic): the columns [sp_arc[a], sp_arc[a + 1]) of arc a touch no column of another arc, so
-  // a forward step takes one column of EVERY arc (two launches for all of them); the separator columns [sp_arc[n_arcs], nT) follow one
-  // by one.  Updates of an arc that land in separator x separator tiles (or the right-hand side of a separator column) go to private
-  // tiles of the arc and are added to the matrix in a fixed order once all arcs are done (k_tchol_merge).  The workgroup lists of
+  // dissection of the tile graph (sparse_symbolic): the order's groups (arcs, then separator sets by level) of one level touch no
+  // column of each other, so a forward step takes one column of EVERY group of the level (two launches for all of them), level after
+  // level.  Updates of a group that land outside the group (in columns of higher levels, or their right-hand side) go to private tiles
+  // of the group and are added to the matrix in a fixed order in front of the next level (k_tchol_merge).  The workgroup lists of
   // all launches (d_sp_wg) are written once, here: sp_fwd / sp_bwd hold every step's offsets into them.
   struct SpStep { int64_t col0; int32_t n_col; int64_t upd0; int32_t n_upd; };
   int sp_n_arcs = 1;
@@ -1321,12 +1321,12 @@ int sparse_symbolic(miba_handle h) {
 
   const int64_t max_tiles = (int64_t)(free_all / 2 / (4096 * sizeof(double)));
 
-  // Elimination order (order_tile_graph, miba_plan.hpp): the tile graph dissected into arcs whose columns are factored side by side,
-  // minimum degree inside.  The factorisation is a chain of steps, each two launches whose latency (about 29 us together) the
-  // work of a narrow column does not fill: the number of arcs trades the length of the arcs' chains (tile rows / arcs) against that
-  // of the separator's (about 8 tile rows per cut at Final-13682) and its denser columns.  The symbolic phase orders the graph for a
-  // few arc counts and keeps the cheapest under tile_order_cost's model (every rank sees the same graph and takes the same
-  // decision); MIBA_SPARSE_ARCS=1..64 fixes the number instead (tests, measurements).
+  // Elimination order (order_tile_graph, miba_plan.hpp): the tile graph dissected into arcs and nested separator sets (groups) whose
+  // columns are factored side by side level by level, minimum degree inside.  The factorisation is a chain of steps, each two launches
+  // whose latency (about 32 us together) the work of a narrow column does not fill: the number of arcs trades the length of the arcs'
+  // chains (tile rows / arcs) against the separators' (levels x rows of a set, about 8 tile rows per cut at Final-13682) and the work
+  // a step holds.  The symbolic phase orders the graph for a few arc counts and keeps the cheapest under tile_order_cost's model (every
+  // rank sees the same graph and takes the same decision); MIBA_SPARSE_ARCS=1..64 fixes the number instead (tests, measurements).
   TileOrder O;
   {
     std::vector<int> cand;

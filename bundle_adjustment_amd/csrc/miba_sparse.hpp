@@ -130,8 +130,8 @@ __device__ __forceinline__ bool tchol_diag_wave(const double* __restrict__ A, co
   return bad;   // (M is lower block triangular: the blocks of As above the diagonal still hold what is left of the tile)
 }
 
-// Column step, first launch.  A launch takes one column of EVERY arc of the dissected order at once (the arcs' columns do not touch
-// each other: sparse_symbolic in miba.hip), a separator column alone: workgroup e = wg[blockIdx.x] = {slot of the column's diagonal tile,
+// Column step, first launch.  A launch takes one column of EVERY group of a level of the dissected order at once (arcs, then nested
+// separator sets level by level; the columns of a level's groups do not touch each other: sparse_symbolic in miba.hip): workgroup e = wg[blockIdx.x] = {slot of the column's diagonal tile,
 // slot of its own tile (one of the tiles below the diagonal, the right-hand-side tile among them), column k, index b of the tile in
 // the column} turns its tile into X = A W = A L^-T.  Every workgroup factors and inverts the diagonal tile itself,
 // on its first wave, while the loads of its own tile are in flight: a launch that does it once and hands W over through memory
