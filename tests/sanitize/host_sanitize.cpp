@@ -3,6 +3,7 @@
 // layout, giant points, filtered observations, several shards) and the BAL loader (threaded parse, binary cache).
 // Built and run by tests/test_sanitizers.py; exits 0 when every check holds.
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
@@ -126,8 +127,71 @@ static void check_loader(const std::string& dir) {
   }
 }
 
+// the exact solve's elimination order (order_tile_graph): bands, rings and graphs without locality, nested separator sets and one
+// set, arc counts up to the limit; checks what the numeric phase relies on: a permutation, contiguous groups, and every column's rows in
+// its own group or a higher level
+static void check_tile_order(int n, int w, bool ring, bool random, int arcs, bool nested, unsigned seed) {
+  const size_t nW = ((size_t)n + 63) / 64;
+  std::vector<uint64_t> adj((size_t)n * nW, 0);
+  auto edge = [&](int u, int v) {
+    if (u == v) return;
+    adj[(size_t)u * nW + (v >> 6)] |= (uint64_t)1 << (v & 63);
+    adj[(size_t)v * nW + (u >> 6)] |= (uint64_t)1 << (u & 63);
+  };
+  std::mt19937 rng(seed);
+  if (random) {
+    for (int i = 0; i < 6 * n; ++i) edge((int)(rng() % n), (int)(rng() % n));
+  } else {
+    for (int u = 0; u < n; ++u)
+      for (int d = 1; d <= w; ++d) {
+        if (u + d < n) edge(u, u + d);
+        else if (ring) edge(u, (u + d) % n);
+      }
+  }
+  miba::TileOrder O;
+  const bool ok = miba::order_tile_graph(adj, n, arcs, (int64_t)1 << 40, 0, O, nested);
+  CHECK(ok);
+  if (!ok) return;
+  std::vector<int> seen(n, 0);
+  for (int v = 0; v < n; ++v) { CHECK(O.pos[v] >= 0 && O.pos[v] < n); seen[O.pos[v]]++; }
+  for (int k = 0; k < n; ++k) CHECK(seen[k] == 1 && O.pos[O.grp[k]] == k);
+  const int nG = (int)O.group_level.size();
+  CHECK((int)O.group_start.size() == nG + 1 && O.group_start[0] == 0 && O.group_start[nG] == n);
+  std::vector<int> g_of(n, -1);
+  for (int g = 0; g < nG; ++g) {
+    CHECK(O.group_start[g] <= O.group_start[g + 1]);
+    if (g) CHECK(O.group_level[g - 1] <= O.group_level[g]);
+    for (int k = O.group_start[g]; k < O.group_start[g + 1]; ++k) g_of[k] = g;
+  }
+  int64_t fill = 0;
+  for (int k = 0; k < n; ++k) {
+    fill += (int64_t)O.col_nodes[k].size();
+    for (int32_t u : O.col_nodes[k]) {
+      const int r = O.pos[u];
+      CHECK(r > k);
+      CHECK(g_of[r] == g_of[k] || O.group_level[g_of[r]] > O.group_level[g_of[k]]);
+    }
+  }
+  CHECK(fill == O.n_off);
+  std::vector<std::vector<int32_t>> steps;
+  std::vector<uint8_t> first;
+  miba::tile_order_steps(O, steps, first);
+  size_t cols = 0;
+  for (auto& ks : steps) cols += ks.size();
+  CHECK(cols == (size_t)n && steps.size() == first.size());
+  CHECK(miba::tile_order_cost(O) > 0.0);
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
+  check_tile_order(400, 6, true, false, 3, true, 1);
+  check_tile_order(1200, 3, false, false, 32, true, 2);
+  check_tile_order(2000, 6, true, false, 48, true, 3);
+  check_tile_order(2000, 6, true, false, 64, false, 4);
+  check_tile_order(257, 9, true, false, 2, true, 5);
+  check_tile_order(300, 0, false, true, 4, true, 6);     // no locality: not dissected
+  check_tile_order(65, 2, false, false, 8, true, 7);
+  check_tile_order(7, 1, false, false, 1, true, 8);
   // serial layout (below 2^18 observations) and threaded layout, 1 and 3 shards, both point orders, giant points
   check_plan(90, 3000, 5, 3, 1, 1, 1);
   check_plan(90, 3000, 5, 3, 3, 0, 2);
