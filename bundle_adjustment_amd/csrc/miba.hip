@@ -1720,7 +1720,8 @@ int backsub_and_candidate(miba_handle h, bool reduce = true, bool with_cost = fa
       } else {
         if (cm)
           hipLaunchKernelGGL(k_mf_backsub_cm, dim3((unsigned)h->n_tiles), dim3(kChunk), 0, h->st, h->d_tiles, h->d_idx, h->d_wl, h->d_oxy, h->d_ct, h->d_cm,
-                             h->d_sc, h->d_sp, h->d_ptrec, h->d_px, h->d_yp, h->d_Xc, h->d_part_tile,
+                             h->d_sc, h->d_sp, h->d_ptrec, h->d_px, with_cost ? (double*)nullptr : h->d_yp /*(the scaled point step: only miba_linear_step hands it out)*/,
+                             h->d_Xc, h->d_part_tile,
                              CmArgs{h->d_cmt, h->d_cms, h->d_cmi, h->d_cmslot, h->d_cam64, nullptr}, (const double2*)h->d_oxy_cm,
                              fold ? (const double*)h->d_ct_cand : (const double*)nullptr);
         else hipLaunchKernelGGL((k_mf_backsub<false, false>), MIBA_BACKSUB_ARGS(h->n_tiles, (const int32_t*)nullptr));

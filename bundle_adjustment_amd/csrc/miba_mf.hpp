@@ -857,7 +857,7 @@ __device__ __forceinline__ void mf_backsub_tile(const Tile& t, const int32_t* __
         const double m1 = u1 + geo.E[3] * z0 + geo.E[4] * z1 + geo.E[5] * z2;
         mcc += om * (m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1));
         if (pos == 0) {
-          yp[3 * p] = z0 * mf_rcp(sp[3 * p]); yp[3 * p + 1] = z1 * mf_rcp(sp[3 * p + 1]); yp[3 * p + 2] = z2 * mf_rcp(sp[3 * p + 2]);
+          if (yp) { yp[3 * p] = z0 * mf_rcp(sp[3 * p]); yp[3 * p + 1] = z1 * mf_rcp(sp[3 * p + 1]); yp[3 * p + 2] = z2 * mf_rcp(sp[3 * p + 2]); }
           const double c0 = rec[0] - z0, c1 = rec[1] - z1, c2 = rec[2] - z2;
           Xc[3 * p] = c0; Xc[3 * p + 1] = c1; Xc[3 * p + 2] = c2;
           const double e0 = rec[0] - c0, e1 = rec[1] - c1, e2 = rec[2] - c2;   // step norm exactly as Ceres: |x - x_cand|

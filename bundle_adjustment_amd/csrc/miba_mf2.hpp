@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Ti
       for (int j = 0; j < kCmSeg; ++j) oo[j] = oxy_cm[cur * kCmSeg + j];
       // (the point scale is only needed for yp, which nothing in the launch waits for: requested here, used after phase 2, so
       // that it is not in registers during phase 1)
-      const double s0 = sp[3 * pg], s1 = sp[3 * pg + 1], s2 = sp[3 * pg + 2];
+      double s0 = 1.0, s1 = 1.0, s2 = 1.0;
+      if (yp) { s0 = sp[3 * pg]; s1 = sp[3 * pg + 1]; s2 = sp[3 * pg + 2]; }   // (yp == null: the LM loop, which has no use for the scaled point step)
       double z0 = 0.0, z1 = 0.0, z2 = 0.0;
       if (on_p) {
         double* pp = buf + my_slot;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256, MIBA_K4CM_WAVES) void k_mf_backsub_cm(const Ti
           }
         }
       }
-      if (on_p) { yp[3 * pg] = z0 * mf_rcp(s0); yp[3 * pg + 1] = z1 * mf_rcp(s1); yp[3 * pg + 2] = z2 * mf_rcp(s2); }
+      if (yp && on_p) { yp[3 * pg] = z0 * mf_rcp(s0); yp[3 * pg + 1] = z1 * mf_rcp(s1); yp[3 * pg + 2] = z2 * mf_rcp(s2); }
       w = w_next;
       my_slot = slot_next;
       sb = sn_rec;
